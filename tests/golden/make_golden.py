@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/* from the REAL reference (run in the build container only).
+
+The reference (viq854/bwbble, /root/reference/mg-aligner) has no tests and no golden vectors
+(SURVEY.md section 4), so parity is pinned by running the reference itself:
+
+  * oracle/Makefile compiles the reference sources where they lie into oracle/_ref/bwbble;
+  * this script drives that binary (`index`, `align -n ...`, `aln2sam`) on small synthetic inputs
+    made by bwbble_amd/tools/bwb_synth.c, and
+  * compiles a throw-away harness (written to a temp dir, never committed) that links the
+    reference's own object files to dump known-answer vectors for O(), O_alphabet() and
+    calculate_d().
+
+Only DATA lands in tests/golden/: the inputs (FASTA/FASTQ), the reference-built index
+(.bwt/.ann), the reference outputs (.aln/.sam) and the known-answer vectors (.npy).
+No reference source text is copied.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = "/root/reference/mg-aligner"
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bwbble")
+REF_OBJ = os.path.join(ROOT, "oracle", "_ref", "obj")
+
+ALIGN_CONFIGS = {
+    # name: extra flags for `bwbble align`
+    "n0": ["-n", "0"],
+    "n1": ["-n", "1"],
+    "n2": ["-n", "2"],
+    "n3": ["-n", "3"],
+    "n5": ["-n", "5"],
+    "n4gap": ["-n", "4", "-o", "2", "-e", "3", "-l", "20", "-k", "1"],
+    "n2pen": ["-n", "2", "-M", "4", "-O", "6", "-E", "4", "-o", "2"],  # mm_score == gape_score bucket collision
+}
+
+HARNESS = r"""
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "bwt.h"
+#include "align.h"
+#include "inexact_match.h"
+#include "io.h"
+void calculate_d(bwt_t* BWT, char* read, const int readLen, diff_lower_bound_t* D, aln_params_t* params);
+int main(int argc, char** argv) {
+	bwt_t* BWT = load_bwt(argv[2], 0);
+	if (strcmp(argv[1], "rank") == 0) {            /* rank <bwt> <pos.u64> <out.u64> */
+		FILE* f = fopen(argv[3], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f) / 8; fseek(f, 0, SEEK_SET);
+		bwtint_t* pos = malloc(8 * n); if (fread(pos, 8, n, f) != (size_t) n) return 2; fclose(f);
+		FILE* o = fopen(argv[4], "wb");
+		for (long q = 0; q < n; q++) {
+			for (int inc = 0; inc < 2; inc++) {
+				bwtint_t occ[16] = { 0 };
+				O_alphabet(BWT, pos[q], 16, occ, inc);
+				fwrite(occ, 8, 16, o);
+			}
+			bwtint_t single[16] = { 0 };
+			for (int c = 1; c < 16; c++) single[c] = O(BWT, c, pos[q]);
+			fwrite(single, 8, 16, o);
+		}
+		fclose(o);
+	} else if (strcmp(argv[1], "dvec") == 0) {     /* dvec <bwt> <fastq> <out.i32> <seed_len> */
+		reads_t* reads = fastq2reads(argv[3]);
+		aln_params_t p; memset(&p, 0, sizeof p); set_default_aln_params(&p);
+		int seed = atoi(argv[5]);
+		FILE* o = fopen(argv[4], "wb");
+		for (unsigned i = 0; i < reads->count; i++) {
+			read_t* r = &reads->reads[i];
+			diff_lower_bound_t* D = calloc(r->len + 1, sizeof *D);
+			diff_lower_bound_t* Ds = calloc(seed + 1, sizeof *Ds);
+			calculate_d(BWT, r->seq, r->len, D, &p);
+			if (r->len > seed) calculate_d(BWT, r->seq, seed, Ds, &p);
+			int hdr[2] = { r->len, seed };
+			fwrite(hdr, 4, 2, o);
+			fwrite(D, sizeof *D, r->len + 1, o);
+			fwrite(Ds, sizeof *Ds, seed + 1, o);
+			free(D); free(Ds);
+		}
+		fclose(o);
+	}
+	return 0;
+}
+"""
+
+
+def run(cmd, **kw):
+    print("+", " ".join(cmd))
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, **kw)
+
+
+def main():
+    if not os.path.isdir(REF_SRC):
+        sys.exit("reference sources not present; golden vectors can only be regenerated in the build container")
+    run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    tmp = tempfile.mkdtemp(prefix="bwb_golden_")
+    synth = os.path.join(tmp, "bwb_synth")
+    run(["gcc", "-O2", "-o", synth, os.path.join(ROOT, "bwbble_amd", "tools", "bwb_synth.c")])
+
+    fa, fq = os.path.join(HERE, "toy.fa"), os.path.join(HERE, "toy.fq")
+    # toy multi-genome: 200 000 fwd chars in 3 records + 4 indel bubbles
+    run([synth, "genome", fa, "200000", "3", "4", "7"])
+    # 600 x 100 bp reads, 1 % substitutions, 2 % of reads with an indel, 1 % of reads with an N
+    run([synth, "reads", fa, fq, "600", "100", "11", "1.0", "2.0", "1.0"])
+    # ragged lengths (36..150, crosses the READ_LENGTH_ALLOC=150 and seed_length=32 edges) incl. N-rich reads
+    fq2 = os.path.join(HERE, "ragged.fq")
+    parts = []
+    for k, (ln, cnt) in enumerate([(36, 40), (51, 40), (75, 40), (125, 40), (150, 40)]):
+        p = os.path.join(tmp, f"r{k}.fq")
+        run([synth, "reads", fa, p, str(cnt), str(ln), str(100 + k), "2.0", "5.0", "20.0"])
+        parts.append(open(p).read())
+    open(fq2, "w").write("".join(parts))
+
+    run([REF_BIN, "index", fa])
+    os.remove(fa + ".ref")  # 400 kB of raw text, not needed by align/aln2sam
+    for name, flags in ALIGN_CONFIGS.items():
+        run([REF_BIN, "align"] + flags + [fa, fq, os.path.join(HERE, f"toy_{name}.aln")])
+    for name in ("n0", "n3", "n4gap"):
+        run([REF_BIN, "align"] + ALIGN_CONFIGS[name] + [fa, fq2, os.path.join(HERE, f"ragged_{name}.aln")])
+    run([REF_BIN, "aln2sam", fa, fq, os.path.join(HERE, "toy_n3.aln"), os.path.join(HERE, "toy_n3.sam")])
+    run([REF_BIN, "aln2sam", fa, fq2, os.path.join(HERE, "ragged_n4gap.aln"), os.path.join(HERE, "ragged_n4gap.sam")])
+
+    # known-answer vectors through a harness linked against the reference's own objects
+    hsrc = os.path.join(tmp, "harness.c")
+    open(hsrc, "w").write(HARNESS)
+    objs = [os.path.join(REF_OBJ, o) for o in os.listdir(REF_OBJ) if o.endswith(".o") and o != "main.o"]
+    hbin = os.path.join(tmp, "harness")
+    run(["gcc", "-w", "-O2", "-std=gnu99", "-fopenmp", "-I", REF_SRC, hsrc] + objs + ["-o", hbin, "-lm"])
+
+    hdr = np.fromfile(fa + ".bwt", dtype=np.uint64, count=5)
+    length, num_words, sa0 = int(hdr[0]), int(hdr[1]), int(hdr[4])
+    words = np.fromfile(fa + ".bwt", dtype=np.uint32, count=num_words, offset=8 * 22)
+    first = (words[::16] >> 28).astype(np.int64)  # first char of every 128-char block
+    rng = np.random.default_rng(5)
+    pos = [2**64 - 1, length - 1, 0, 1, 127, 128, 129, length - 2, sa0, sa0 - 1, sa0 + 1, (sa0 // 128) * 128]
+    for code in (5, 9, 11, 13, 0, 10):  # blocks starting with an uncounted 3-base code, '$' and N
+        blocks = np.nonzero(first == code)[0][:6]
+        for b in blocks:
+            pos += [int(b) * 128, int(b) * 128 + 1, min(int(b) * 128 + 127, length - 1), min(int(b) * 128 + 60, length - 1)]
+    nblk = (length + 127) // 128
+    for b in rng.integers(0, nblk, 300):
+        pos += [int(b) * 128, max(int(b) * 128 - 1, 0)]
+    pos += [int(v) for v in rng.integers(0, length, 6000)]
+    pos = np.array([p for p in pos if p == 2**64 - 1 or 0 <= p < length], dtype=np.uint64)
+    ppath, opath = os.path.join(tmp, "pos.u64"), os.path.join(tmp, "rank.u64")
+    pos.tofile(ppath)
+    run([hbin, "rank", fa + ".bwt", ppath, opath])
+    out = np.fromfile(opath, dtype=np.uint64).reshape(len(pos), 3, 16)
+    np.save(os.path.join(HERE, "rank_pos.npy"), pos)
+    np.save(os.path.join(HERE, "rank_O_alphabet_inc0.npy"), out[:, 0, :])
+    np.save(os.path.join(HERE, "rank_O_alphabet_inc1.npy"), out[:, 1, :])
+    np.save(os.path.join(HERE, "rank_O_single.npy"), out[:, 2, :])
+
+    for tag, path in (("toy", fq), ("ragged", fq2)):
+        dpath = os.path.join(tmp, f"d_{tag}.i32")
+        run([hbin, "dvec", fa + ".bwt", path, dpath, "32"])
+        np.save(os.path.join(HERE, f"dvec_{tag}.npy"), np.fromfile(dpath, dtype=np.int32))
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

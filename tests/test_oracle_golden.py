@@ -1,0 +1,65 @@
+"""Pins the CPU oracle (oracle/bwb_oracle.c) to golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from golden.make_golden import ALIGN_CONFIGS
+
+
+def test_rank_known_answers(oracle, golden):
+    idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"))
+    pos = np.load(os.path.join(golden, "rank_pos.npy"))
+    for inc in (0, 1):
+        ref = np.load(os.path.join(golden, f"rank_O_alphabet_inc{inc}.npy"))
+        got = oracle.O_alphabet(idx, pos, inc)
+        assert np.array_equal(got[:, 1:], ref[:, 1:])
+    ref = np.load(os.path.join(golden, "rank_O_single.npy"))
+    sub = slice(0, 1500)
+    assert np.array_equal(oracle.O_single(idx, pos[sub])[:, 1:], ref[sub, 1:])
+
+
+def _read_fastq_codes(path):
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in (("A", 0), ("G", 1), ("C", 2), ("T", 3)):
+        lut[ord(ch)] = v
+        lut[ord(ch.lower())] = v
+    lines = open(path).read().split("\n")
+    return [lut[np.frombuffer(lines[i].encode(), dtype=np.uint8)] for i in range(1, len(lines) - 1, 4)]
+
+
+@pytest.mark.parametrize("tag", ["toy", "ragged"])
+def test_calculate_d_known_answers(oracle, golden, tag):
+    idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"))
+    reads = _read_fastq_codes(os.path.join(golden, f"{tag}.fq"))
+    vec = np.load(os.path.join(golden, f"dvec_{tag}.npy"))
+    p = oracle.params()
+    off = 0
+    for r in reads[:150]:
+        ln, seed = int(vec[off]), int(vec[off + 1]); off += 2
+        assert ln == len(r)
+        D = vec[off:off + 2 * (ln + 1)].reshape(ln + 1, 2); off += 2 * (ln + 1)
+        Ds = vec[off:off + 2 * (seed + 1)].reshape(seed + 1, 2); off += 2 * (seed + 1)
+        assert np.array_equal(oracle.calculate_d(idx, r, p), D)
+        if ln > seed:
+            assert np.array_equal(oracle.calculate_d(idx, r[:seed], p), Ds)
+
+
+@pytest.mark.parametrize("name", sorted(ALIGN_CONFIGS))
+def test_aln_bytes_match_reference(oracle, golden, tmp_path, name):
+    out = str(tmp_path / "o.aln")
+    p = oracle.params(ALIGN_CONFIGS[name])
+    n, st, _ = oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "toy.fq"), out, p)
+    assert n == 600
+    assert open(out, "rb").read() == open(os.path.join(golden, f"toy_{name}.aln"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap"])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_ragged_reads_match_reference(oracle, golden, tmp_path, name, threads):
+    out = str(tmp_path / "o.aln")
+    p = oracle.params(ALIGN_CONFIGS[name] + ["-t", str(threads)])
+    n, _, _ = oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "ragged.fq"), out, p)
+    assert n == 200
+    assert open(out, "rb").read() == open(os.path.join(golden, f"ragged_{name}.aln"), "rb").read()
