@@ -1,0 +1,291 @@
+"""bwbble_amd - host-side Python mirror of the C-ABI in include/bwbble_hip.h (ctypes, no torch types).
+
+The product is libbwbble_hip.so (hand-written HIP for gfx950) plus the C host tools in
+bwbble_amd/host; this module only binds the library for tests and bench.py.  It fails loudly when
+the library is missing or no GPU is present: there is no CPU path here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbwbble_hip.so")
+HOST_BIN = os.path.join(HERE, "bin", "bwbble")
+SYNTH_BIN = os.path.join(HERE, "bin", "bwb_synth")
+
+EXPORTS = [
+    "bwb_hip_device_count", "bwb_hip_last_error", "bwb_default_params", "bwb_hip_ctx_create", "bwb_hip_ctx_destroy",
+    "bwb_hip_align_batch", "bwb_hip_batch_upload", "bwb_hip_batch_run", "bwb_hip_batch_result", "bwb_hip_get_stats",
+    "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_set_sa", "bwb_hip_locate",
+]
+
+
+class Params(C.Structure):
+    """bwb_params == aln_params_t (mg-aligner/align.h:48-79)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "max_diff", "max_gapo", "max_gape", "max_entries", "mm_score", "gapo_score", "gape_score",
+        "seed_length", "max_diff_seed", "max_best", "no_indel_length", "matched_Ncontig", "use_precalc",
+        "is_multiref", "n_threads")]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("aln_off", C.POINTER(C.c_uint64)), ("alns", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("visits_single", C.c_uint64), ("visits_alphabet", C.c_uint64), ("heap_pops", C.c_uint64),
+                ("heap_pushes", C.c_uint64), ("n_alignments", C.c_uint64), ("n_overflow_reads", C.c_uint64),
+                ("ms_calc_d", C.c_double), ("ms_search", C.c_double), ("ms_total", C.c_double),
+                ("launches_calc_d", C.c_uint32), ("launches_search", C.c_uint32)]
+
+
+ALN_DTYPE = np.dtype([("L", "<u8"), ("U", "<u8"), ("score", "u1"), ("num_mm", "u1"), ("num_gapo", "u1"),
+                      ("num_gape", "u1"), ("aln_length", "<u4"), ("gap_run", "<u2", (4,))])
+assert ALN_DTYPE.itemsize == 32
+
+_FLAG = {"-M": "mm_score", "-O": "gapo_score", "-E": "gape_score", "-n": "max_diff", "-k": "max_diff_seed",
+         "-o": "max_gapo", "-e": "max_gape", "-l": "seed_length", "-m": "max_entries", "-t": "n_threads"}
+
+_lib = None
+
+
+class BwbError(RuntimeError):
+    pass
+
+
+def build():
+    """Compiles the HIP library and the host tools in-tree (hipcc --offload-arch=gfx950)."""
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BwbError(f"{LIB_PATH} is missing: run `make -C bwbble_amd` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.bwb_hip_last_error.restype = C.c_char_p
+        L.bwb_hip_ctx_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.bwb_hip_ctx_destroy.argtypes = [C.c_void_p]
+        L.bwb_hip_batch_upload.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.bwb_hip_batch_run.argtypes = [C.c_void_p]
+        L.bwb_hip_batch_result.argtypes = [C.c_void_p, C.POINTER(Result)]
+        L.bwb_hip_align_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Result)]
+        L.bwb_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.bwb_hip_calc_d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bwb_hip_rank16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.bwb_hip_rank_bench.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.bwb_hip_set_sa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.bwb_hip_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise BwbError(f"bwbble_hip error {rc}: {lib().bwb_hip_last_error().decode()}")
+
+
+def device_count():
+    return lib().bwb_hip_device_count()
+
+
+def params(flags=()):
+    """Defaults of set_default_aln_params (align.c:22-38) + `bwbble align` style flags (main.c:100-117)."""
+    p = Params()
+    lib().bwb_default_params(C.byref(p))
+    flags = list(flags)
+    i = 0
+    while i < len(flags):
+        if flags[i] == "-S":
+            p.is_multiref = 0
+            i += 1
+        elif flags[i] == "-P":
+            p.use_precalc = 1
+            i += 1
+        else:
+            setattr(p, _FLAG[flags[i]], int(flags[i + 1]))
+            i += 2
+    return p
+
+
+class BwtFile:
+    """In-memory bwt_t (bwt.h:19-40) read from a reference-format .bwt file (bwt.c:66-82)."""
+
+    def __init__(self, path, load_sa=False):
+        hdr = np.fromfile(path, dtype="<u8", count=22)
+        self.hdr = hdr[:5].copy()
+        self.length, self.num_words, self.num_sa, self.num_occ, self.sa0_index = (int(v) for v in hdr[:5])
+        self.C = hdr[5:22].copy()
+        off = 22 * 8
+        self.bwt = np.fromfile(path, dtype="<u4", count=self.num_words, offset=off)
+        off += 4 * self.num_words
+        self.O = np.fromfile(path, dtype="<u8", count=self.num_occ * 16, offset=off)
+        off += 8 * self.num_occ * 16
+        self.SA = np.fromfile(path, dtype="<u8", count=self.num_sa, offset=off) if load_sa else None
+
+
+class Context:
+    """One GPU context (bwb_hip_ctx): device-resident FM-index + batch state."""
+
+    def __init__(self, bwt, device=0):
+        if isinstance(bwt, str):
+            bwt = BwtFile(bwt)
+        if device_count() < 1:
+            raise BwbError("no HIP device visible: the alignment path has no CPU fallback")
+        self.bwt = bwt
+        self._h = C.c_void_p()
+        _chk(lib().bwb_hip_ctx_create(device, bwt.hdr.ctypes.data, bwt.C.ctypes.data, bwt.bwt.ctypes.data,
+                                      bwt.O.ctypes.data, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().bwb_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- batch API ------------------------------------------------------------------------------
+    def upload(self, p, seqs, lens):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        if seqs.ndim != 2 or len(lens) != seqs.shape[0]:
+            raise ValueError("seqs must be (n_reads, stride) uint8 with one length per row")
+        self._keep = (seqs, lens)
+        _chk(lib().bwb_hip_batch_upload(self._h, C.byref(p), seqs.ctypes.data, lens.ctypes.data, seqs.shape[0], max(seqs.shape[1], 1)))
+
+    def run(self):
+        _chk(lib().bwb_hip_batch_run(self._h))
+
+    def result(self):
+        r = Result()
+        _chk(lib().bwb_hip_batch_result(self._h, C.byref(r)))
+        n = r.n_reads
+        off = np.ctypeslib.as_array(r.aln_off, shape=(n + 1,)).copy()
+        total = int(off[n])
+        alns = np.frombuffer(C.string_at(r.alns, total * 32), dtype=ALN_DTYPE) if total else np.zeros(0, dtype=ALN_DTYPE)
+        return off, alns
+
+    def align(self, p, seqs, lens):
+        self.upload(p, seqs, lens)
+        self.run()
+        return self.result()
+
+    def stats(self):
+        s = Stats()
+        _chk(lib().bwb_hip_get_stats(self._h, C.byref(s)))
+        return s
+
+    def calc_d(self, p, seqs, lens):
+        """D / D_seed of every read as (n, maxlen+1, 2) and (n, seed_length+1, 2) int32 (num_diff, sa_intv_width)."""
+        self.upload(p, seqs, lens)
+        n, maxlen = len(lens), int(max(lens)) if len(lens) else 0
+        D = np.zeros((n, maxlen + 1, 2), dtype=np.int32)
+        Ds = np.zeros((n, p.seed_length + 1, 2), dtype=np.int32)
+        _chk(lib().bwb_hip_calc_d(self._h, D.ctypes.data, Ds.ctypes.data))
+        return D, Ds
+
+    # -- rank -----------------------------------------------------------------------------------
+    def rank16(self, pos, inc=0, exact=False):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros((len(pos), 16), dtype=np.uint64)
+        _chk(lib().bwb_hip_rank16(self._h, pos.ctypes.data, len(pos), inc, int(exact), out.ctypes.data))
+        return out
+
+    def rank_bench(self, n, iters=5, seed=1):
+        ms, cs = C.c_double(), C.c_uint64()
+        _chk(lib().bwb_hip_rank_bench(self._h, n, iters, seed, C.byref(ms), C.byref(cs)))
+        return ms.value, cs.value
+
+    def set_sa(self, SA):
+        SA = np.ascontiguousarray(SA, dtype=np.uint64)
+        _chk(lib().bwb_hip_set_sa(self._h, SA.ctypes.data, len(SA)))
+
+    def locate(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(len(rows), dtype=np.uint64)
+        _chk(lib().bwb_hip_locate(self._h, rows.ctypes.data, len(rows), out.ctypes.data))
+        return out
+
+
+# -- formats ------------------------------------------------------------------------------------
+
+def encode_reads(ascii_reads):
+    """read->seq codes of fastq2reads (io.c:467; io.h:112-130): A0 G1 C2 T3, anything else 4."""
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in (("A", 0), ("G", 1), ("C", 2), ("T", 3)):
+        lut[ord(ch)] = v
+        lut[ord(ch.lower())] = v
+    lens = np.array([len(r) for r in ascii_reads], dtype=np.uint16)
+    stride = int(lens.max()) if len(lens) else 1
+    seqs = np.full((len(ascii_reads), max(stride, 1)), 4, dtype=np.uint8)
+    for i, r in enumerate(ascii_reads):
+        seqs[i, :len(r)] = lut[np.frombuffer(r.encode(), dtype=np.uint8)]
+    return seqs, lens
+
+
+def read_fastq(path, max_reads=0):
+    """Sequence lines of a 4-line FASTQ (the subset of fastq2reads, io.c:410-515, that align needs)."""
+    out = []
+    with open(path) as f:
+        while True:
+            name = f.readline()
+            if not name:
+                break
+            if not name.startswith("@"):
+                continue
+            seq = f.readline().rstrip("\n")
+            f.readline()
+            f.readline()
+            out.append(seq)
+            if max_reads and len(out) >= max_reads:
+                break
+    return out
+
+
+def aln_path(rec):
+    """Edit path bytes (index 0 = first backward-search step) of one hit from its gap runs."""
+    alen = int(rec["aln_length"])
+    path = np.zeros(256 + 8, dtype=np.uint8)
+    for run in rec["gap_run"]:
+        run = int(run)
+        if run == 0xFFFF:
+            continue
+        start, ln, is_del = run & 0xFF, (run >> 8) & 0x7F, run >> 15
+        path[start:start + ln] = 2 if is_del else 1
+    return path[:alen]
+
+
+def aln_bytes(aln_off, alns):
+    """Serialises hits exactly like alns2alnf_bin (align.c:345-382): the bytes of a .aln file."""
+    out = bytearray()
+    i32 = lambda v: int(v).to_bytes(4, "little", signed=True)
+    for r in range(len(aln_off) - 1):
+        lo, hi = int(aln_off[r]), int(aln_off[r + 1])
+        out += i32(hi - lo)
+        for rec in alns[lo:hi]:
+            out += i32(rec["score"]) + int(rec["L"]).to_bytes(8, "little") + int(rec["U"]).to_bytes(8, "little")
+            out += i32(rec["num_mm"]) + i32(rec["num_gapo"]) + i32(rec["num_gape"]) + i32(rec["aln_length"])
+            path = aln_path(rec)
+            if len(path) == 0:
+                out += i32(0)
+                continue
+            pairs = []
+            state, count = int(path[-1]), 1
+            for s in path[-2::-1]:
+                if int(s) == state:
+                    count += 1
+                else:
+                    pairs.append(state | (count << 2))
+                    state, count = int(s), 1
+            pairs.append(state | (count << 2))
+            out += i32(len(pairs))
+            for v in pairs:
+                out += i32(v)
+    return bytes(out)

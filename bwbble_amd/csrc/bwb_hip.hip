@@ -1,0 +1,551 @@
+/*
+ * bwb_hip.hip - C-ABI implementation of include/bwbble_hip.h (libbwbble_hip.so), MI355X / gfx950 only.
+ *
+ * Host orchestration of one batch (replaces the per-batch body of align_reads_inexact_parallel,
+ * mg-aligner/inexact_match.c:103-165):
+ *   1. k_calc_d over all reads (work-stealing octets);
+ *   2. k_search over all reads with the class-0 per-octet scratch; reads whose heap / interval list /
+ *      hit list did not fit are re-run -- still on the GPU -- in class 1, then class 2 (class 2 holds
+ *      max_entries heap entries, the reference's own bound, inexact_match.c:299);
+ *   3. hits gathered into read order.
+ * There is no CPU fallback anywhere in this file.
+ */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/bwbble_hip.h"
+#include "bwb_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &m) { g_err = m; return code; }
+#define HIPCHK(x)                                                                                         \
+	do {                                                                                                  \
+		hipError_t e_ = (x);                                                                              \
+		if (e_ != hipSuccess) return fail(BWB_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));  \
+	} while (0)
+
+struct ScratchClass {
+	void *mem = nullptr;
+	size_t bytes = 0, slot_bytes = 0;
+	Scratch sc{};
+	uint32_t blocks = 0;
+};
+
+struct bwb_hip_ctx {
+	int device = 0, num_cu = 0;
+	hipStream_t stream = nullptr;
+	DevIndex ix{};
+	uint4 *d_buckets = nullptr;
+	uint64_t sa0_index = 0, num_sa = 0;
+	uint64_t *d_SA = nullptr;
+	/* batch */
+	bool uploaded = false, ran = false;
+	bwb_params p{};
+	KParams kp{};
+	uint32_t n_reads = 0, stride = 0, maxlen = 0;
+	size_t cap_reads = 0, cap_readbytes = 0, cap_dbuf = 0;
+	uint8_t *d_reads = nullptr, *d_dbuf = nullptr, *d_status = nullptr;
+	uint16_t *d_lens = nullptr;
+	uint32_t *d_counter = nullptr, *d_worklist = nullptr, *d_n = nullptr;
+	uint64_t *d_off = nullptr, *d_dstoff = nullptr;
+	uint4 *d_log = nullptr, *d_sorted = nullptr;
+	unsigned long long *d_count = nullptr, *d_stats = nullptr;
+	uint64_t log_cap = 0, sorted_cap = 0;
+	uint32_t dstride = 0, dseed_off = 0;
+	ScratchClass cls[3];
+	std::vector<uint8_t> h_status;
+	std::vector<uint64_t> h_aln_off;
+	std::vector<bwb_aln> h_alns;
+	bwb_stats stats{};
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" const char *bwb_hip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bwb_hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" void bwb_default_params(bwb_params *p) { /* set_default_aln_params, align.c:22-38 */
+	memset(p, 0, sizeof(*p));
+	p->gape_score = 4; p->gapo_score = 11; p->mm_score = 3; p->max_diff = 0; p->max_gape = 6; p->max_gapo = 1;
+	p->seed_length = 32; p->max_diff_seed = 2; p->max_entries = 3000000; p->use_precalc = 0; p->matched_Ncontig = 0;
+	p->is_multiref = 1; p->max_best = 30; p->no_indel_length = 5; p->n_threads = 1;
+}
+
+extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                                  const uint64_t *O, bwb_hip_ctx **out) {
+	if (!hdr || !C || !bwt || !O || !out) return fail(BWB_E_ARG, "ctx_create: null argument");
+	const uint64_t length = hdr[0], num_words = hdr[1], num_occ = hdr[3];
+	const uint64_t nblk = (length + 127) / 128;
+	if (length < 2 || num_occ != nblk || num_words != (length + 7) / 8) return fail(BWB_E_ARG, "ctx_create: inconsistent .bwt header");
+	const uint64_t nsb = (nblk + (1ull << BWB_SB_SHIFT) - 1) >> BWB_SB_SHIFT;
+	if (nsb > BWB_NSB_MAX) return fail(BWB_E_ARG, "ctx_create: index larger than 2^34 characters");
+	HIPCHK(hipSetDevice(device));
+	bwb_hip_ctx *c = new bwb_hip_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+	c->num_cu = prop.multiProcessorCount;
+	HIPCHK(hipStreamCreate(&c->stream));
+	HIPCHK(hipEventCreate(&c->ev0));
+	HIPCHK(hipEventCreate(&c->ev1));
+	HIPCHK(hipMalloc(&c->d_buckets, nblk * 128));
+	HIPCHK(hipMalloc(&c->d_counter, 64));
+	HIPCHK(hipMalloc(&c->d_count, 64));
+	HIPCHK(hipMalloc(&c->d_stats, sizeof(unsigned long long) * 16));
+
+	/* superblock base table */
+	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
+	memset(&c->ix, 0, sizeof(c->ix));
+	for (uint64_t sb = 0; sb < nsb; sb++) {
+		const uint64_t blk = sb << BWB_SB_SHIFT;
+		const uint32_t first = bwt[blk * 16] >> 28;
+		for (int j = 1; j < 16; j++) sbcount[sb * 16 + j] = O[blk * 16 + j] - (first == (uint32_t)j ? 1 : 0);
+	}
+	for (uint64_t sb = 0; sb < BWB_NSB_MAX; sb++)
+		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
+	for (int j = 0; j < 16; j++) { c->ix.base[BWB_ROW_NEG][j] = C[j]; c->ix.base[BWB_ROW_END][j] = C[j + 1]; }
+	c->ix.buckets = c->d_buckets;
+	c->ix.length = length;
+	c->ix.nblk = nblk;
+	c->sa0_index = hdr[4];
+
+	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk */
+	const uint64_t CH = 1ull << 20;
+	uint32_t *d_bwt = nullptr; uint64_t *d_O = nullptr, *d_sbc = nullptr;
+	HIPCHK(hipMalloc(&d_bwt, std::min(CH, nblk) * 64));
+	HIPCHK(hipMalloc(&d_O, std::min(CH, nblk) * 128));
+	HIPCHK(hipMalloc(&d_sbc, sbcount.size() * 8));
+	HIPCHK(hipMemcpy(d_sbc, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice));
+	for (uint64_t b0 = 0; b0 < nblk; b0 += CH) {
+		const uint64_t nb = std::min(CH, nblk - b0);
+		const uint64_t w0 = b0 * 16, nw = std::min(nb * 16, num_words - w0);
+		HIPCHK(hipMemcpy(d_bwt, bwt + w0, nw * 4, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(d_O, O + b0 * 16, nb * 128, hipMemcpyHostToDevice));
+		const uint64_t nthreads = nb * 8;
+		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt, d_O, b0, nb, nw, d_sbc, c->d_buckets);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	hipFree(d_bwt); hipFree(d_O); hipFree(d_sbc);
+	*out = c;
+	return BWB_OK;
+}
+
+static void free_batch(bwb_hip_ctx *c) {
+	hipFree(c->d_reads); hipFree(c->d_lens); hipFree(c->d_dbuf); hipFree(c->d_status); hipFree(c->d_worklist);
+	hipFree(c->d_n); hipFree(c->d_off); hipFree(c->d_dstoff);
+	c->d_reads = c->d_dbuf = c->d_status = nullptr; c->d_lens = nullptr; c->d_worklist = c->d_n = nullptr; c->d_off = c->d_dstoff = nullptr;
+	c->cap_reads = c->cap_readbytes = c->cap_dbuf = 0;
+}
+
+extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
+	if (!c) return;
+	hipSetDevice(c->device);
+	free_batch(c);
+	for (auto &k : c->cls) hipFree(k.mem);
+	hipFree(c->d_log); hipFree(c->d_sorted); hipFree(c->d_buckets); hipFree(c->d_counter); hipFree(c->d_count);
+	hipFree(c->d_stats); hipFree(c->d_SA);
+	if (c->ev0) hipEventDestroy(c->ev0);
+	if (c->ev1) hipEventDestroy(c->ev1);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+static uint32_t pad16(uint32_t v) { return (v + 15u) & ~15u; }
+
+/* per-octet LDS bytes of k_search and its sub-array paddings */
+static void search_lds(const bwb_hip_ctx *c, uint32_t &oct_bytes, uint32_t &lpad, uint32_t &spad, uint32_t &nbpad, size_t &total) {
+	lpad = pad16(c->maxlen ? c->maxlen : 1);
+	spad = pad16(c->kp.seed_length > 0 ? (uint32_t)c->kp.seed_length : 1);
+	nbpad = pad16((uint32_t)c->kp.num_buckets) ;
+	oct_bytes = 32 + 4 * nbpad + lpad + spad + lpad;
+	oct_bytes = pad16(oct_bytes);
+	total = (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)BWB_OCTS_PER_BLOCK * oct_bytes;
+}
+static size_t calcd_lds(const bwb_hip_ctx *c) {
+	return (size_t)BWB_BASE_ROWS * 16 * 8 + BWB_OCTS_PER_BLOCK * 4 * 8 + (size_t)BWB_OCTS_PER_BLOCK * pad16(c->stride);
+}
+
+static int ensure_class(bwb_hip_ctx *c, int k) {
+	ScratchClass &s = c->cls[k];
+	uint32_t nchunks, acap, lcap, blocks;
+	if (k == 0) {
+		uint32_t o, l, sp, nb; size_t lds;
+		search_lds(c, o, l, sp, nb, lds);
+		int occ = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search, BWB_BLOCK, lds) != hipSuccess || occ < 1) occ = 2;
+		if (occ > 4) occ = 4;
+		blocks = (uint32_t)(c->num_cu * occ);
+		nchunks = 1024; acap = 256; lcap = 2048;
+	} else if (k == 1) {
+		blocks = 32; nchunks = 32768; acap = 4096; lcap = 65536;
+	} else {
+		blocks = 4;
+		nchunks = (uint32_t)((uint64_t)c->kp.max_entries / 16 + 2 * (uint64_t)c->kp.num_buckets + 16);
+		if (nchunks < 65536) nchunks = 65536;
+		acap = 1u << 16; lcap = 1u << 20;
+	}
+	const size_t slot_bytes = (size_t)nchunks * 512 + (size_t)nchunks * 4 + (size_t)acap * 32 + (size_t)lcap * 32;
+	const size_t slots = (size_t)blocks * BWB_OCTS_PER_BLOCK;
+	const size_t bytes = slot_bytes * slots;
+	if (s.mem && s.bytes >= bytes && s.sc.nchunks == nchunks && s.blocks == blocks) return BWB_OK;
+	if (s.mem) { hipFree(s.mem); s.mem = nullptr; }
+	size_t fr = 0, tot = 0;
+	hipMemGetInfo(&fr, &tot);
+	if (bytes + (1ull << 30) > fr) return fail(BWB_E_HIP, "not enough device memory for the per-read scratch (class " + std::to_string(k) + ")");
+	HIPCHK(hipMalloc(&s.mem, bytes));
+	s.bytes = bytes; s.slot_bytes = slot_bytes; s.blocks = blocks;
+	unsigned char *base = (unsigned char *)s.mem;
+	s.sc.ent = (uint4 *)base; base += slots * (size_t)nchunks * 512;
+	s.sc.cprev = (uint32_t *)base; base += slots * (size_t)nchunks * 4;
+	s.sc.alns = (uint4 *)base; base += slots * (size_t)acap * 32;
+	s.sc.lists = (ulonglong2 *)base;
+	s.sc.nchunks = nchunks; s.sc.acap = acap; s.sc.lcap = lcap;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                                    uint32_t n_reads, uint32_t stride) {
+	if (!c || !p || (n_reads && (!reads_fwd || !lens)) || stride == 0) return fail(BWB_E_ARG, "batch_upload: bad argument");
+	if (!p->is_multiref) return fail(BWB_E_ARG, "single-genome mode (-S) is not supported by the GPU path yet");
+	if (p->use_precalc) return fail(BWB_E_ARG, "precalculated intervals (-P) are not supported by the GPU path yet");
+	if (p->max_gapo < 0 || p->max_gapo > 4) return fail(BWB_E_ARG, "max_gapo (-o) must be in [0,4] on the GPU path");
+	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
+	if (p->seed_length < 0 || p->seed_length > 255) return fail(BWB_E_ARG, "seed_length must be in [0,255]");
+	if (p->mm_score < 0 || p->gapo_score < 0 || p->gape_score < 0) return fail(BWB_E_ARG, "negative penalties are not supported");
+	const int nb = (p->max_diff + 1) * p->mm_score + (p->max_gapo + 1) * p->gapo_score + (p->max_gape + 1) * p->gape_score; /* heap_init :513 */
+	if (nb < 1 || nb > 128) return fail(BWB_E_ARG, "score range (heap buckets) must be in [1,128]");
+	if (p->max_entries < 1) return fail(BWB_E_ARG, "max_entries must be positive");
+	uint32_t maxlen = 0;
+	for (uint32_t i = 0; i < n_reads; i++) maxlen = std::max<uint32_t>(maxlen, lens[i]);
+	if (maxlen > 255 || maxlen > stride) return fail(BWB_E_ARG, "reads longer than 255 bases (or than stride) are not supported (aln_entry_t.i is 8-bit, align.h:104)");
+	HIPCHK(hipSetDevice(c->device));
+	c->p = *p;
+	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
+	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb };
+	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
+	c->dseed_off = pad16(maxlen ? maxlen : 1);
+	c->dstride = c->dseed_off + pad16(p->seed_length ? p->seed_length : 1);
+	const size_t nr = n_reads ? n_reads : 1;
+	if (nr > c->cap_reads || nr * stride > c->cap_readbytes || nr * c->dstride > c->cap_dbuf) {
+		free_batch(c);
+		c->cap_reads = nr; c->cap_readbytes = nr * stride; c->cap_dbuf = nr * c->dstride;
+		HIPCHK(hipMalloc(&c->d_reads, c->cap_readbytes));
+		HIPCHK(hipMalloc(&c->d_lens, nr * 2));
+		HIPCHK(hipMalloc(&c->d_dbuf, c->cap_dbuf));
+		HIPCHK(hipMalloc(&c->d_status, nr));
+		HIPCHK(hipMalloc(&c->d_worklist, nr * 4));
+		HIPCHK(hipMalloc(&c->d_n, nr * 4));
+		HIPCHK(hipMalloc(&c->d_off, nr * 8));
+		HIPCHK(hipMalloc(&c->d_dstoff, nr * 8));
+	}
+	if (n_reads) {
+		HIPCHK(hipMemcpyAsync(c->d_reads, reads_fwd, (size_t)n_reads * stride, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->d_lens, lens, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
+	}
+	/* hit log: start at 8 records per read, grown on demand */
+	const uint64_t want = std::max<uint64_t>((uint64_t)nr * 8, 1u << 16);
+	if (c->log_cap < want) {
+		hipFree(c->d_log);
+		c->d_log = nullptr;
+		HIPCHK(hipMalloc(&c->d_log, want * 32));
+		c->log_cap = want;
+	}
+	int rc = ensure_class(c, 0);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->uploaded = true; c->ran = false;
+	return BWB_OK;
+}
+
+static Batch make_batch(bwb_hip_ctx *c, const uint32_t *worklist, uint32_t n_work) {
+	Batch b;
+	b.reads = c->d_reads; b.lens = c->d_lens; b.n_reads = c->n_reads; b.stride = c->stride;
+	b.dbuf = c->d_dbuf; b.dstride = c->dstride; b.dseed_off = c->dseed_off;
+	b.worklist = worklist; b.n_work = n_work; b.counter = c->d_counter; b.status = c->d_status;
+	return b;
+}
+
+/* reads whose status == want -> device worklist; returns count */
+static int collect(bwb_hip_ctx *c, uint8_t want, std::vector<uint32_t> &ids) {
+	c->h_status.resize(c->n_reads);
+	HIPCHK(hipMemcpy(c->h_status.data(), c->d_status, c->n_reads, hipMemcpyDeviceToHost));
+	ids.clear();
+	for (uint32_t i = 0; i < c->n_reads; i++) if (c->h_status[i] == want) ids.push_back(i);
+	if (!ids.empty()) HIPCHK(hipMemcpy(c->d_worklist, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+	return BWB_OK;
+}
+
+static int launch_calc_d(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work, int32_t *dbgD, int32_t *dbgDs) {
+	ScratchClass &s = c->cls[k];
+	Scratch sc = s.sc;
+	/* calculate_d only needs the two interval lists: give it the whole slot */
+	sc.lists = (ulonglong2 *)s.mem;
+	sc.lcap = (uint32_t)std::min<size_t>(s.slot_bytes / 32, 1u << 24);
+	Batch b = make_batch(c, wl, n_work);
+	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
+	const uint32_t grid = std::min<uint32_t>(s.blocks, (n_work + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK);
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	hipLaunchKernelGGL(k_calc_d, dim3(grid ? grid : 1), dim3(BWB_BLOCK), calcd_lds(c), c->stream, c->ix, b, c->kp, sc, dbgD, dbgDs,
+	                   c->maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	c->stats.ms_calc_d += ms; c->stats.launches_calc_d++;
+	return BWB_OK;
+}
+
+static int run_calc_d(bwb_hip_ctx *c, int32_t *dbgD, int32_t *dbgDs) {
+	int rc = launch_calc_d(c, 0, nullptr, c->n_reads, dbgD, dbgDs);
+	if (rc) return rc;
+	std::vector<uint32_t> ids;
+	for (int k = 1; k <= 2; k++) {
+		rc = collect(c, ST_SCRATCH_OVF, ids);
+		if (rc) return rc;
+		if (ids.empty()) return BWB_OK;
+		c->stats.n_overflow_reads += ids.size();
+		rc = ensure_class(c, k);
+		if (rc) return rc;
+		rc = launch_calc_d(c, k, c->d_worklist, (uint32_t)ids.size(), dbgD, dbgDs);
+		if (rc) return rc;
+	}
+	rc = collect(c, ST_SCRATCH_OVF, ids);
+	if (rc) return rc;
+	if (!ids.empty()) return fail(BWB_E_OVERFLOW, "calculate_d: SA-interval list exceeded the largest scratch class");
+	return BWB_OK;
+}
+
+static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work) {
+	ScratchClass &s = c->cls[k];
+	Batch b = make_batch(c, wl, n_work);
+	OutBuf ob{ c->d_log, c->d_count, c->log_cap, c->d_off, c->d_n };
+	uint32_t o, l, sp, nb; size_t lds;
+	search_lds(c, o, l, sp, nb, lds);
+	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
+	const uint32_t grid = std::min<uint32_t>(s.blocks, (n_work + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK);
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	hipLaunchKernelGGL(k_search, dim3(grid ? grid : 1), dim3(BWB_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats, o, l, sp, nb);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	c->stats.ms_search += ms; c->stats.launches_search++;
+	return BWB_OK;
+}
+
+/* grows the hit log if reads were refused for lack of room, then re-runs them in class k */
+static int rerun_out_overflow(bwb_hip_ctx *c, int k) {
+	std::vector<uint32_t> ids;
+	for (int guard = 0; guard < 40; guard++) {
+		int rc = collect(c, ST_OUT_OVF, ids);
+		if (rc) return rc;
+		if (ids.empty()) return BWB_OK;
+		unsigned long long cnt = 0;
+		HIPCHK(hipMemcpy(&cnt, c->d_count, 8, hipMemcpyDeviceToHost));
+		const uint64_t valid = std::min<uint64_t>(cnt, c->log_cap);
+		const uint64_t ncap = c->log_cap * 4;
+		uint4 *nl = nullptr;
+		HIPCHK(hipMalloc(&nl, ncap * 32));
+		HIPCHK(hipMemcpy(nl, c->d_log, valid * 32, hipMemcpyDeviceToDevice));
+		hipFree(c->d_log);
+		c->d_log = nl; c->log_cap = ncap;
+		cnt = valid;
+		HIPCHK(hipMemcpy(c->d_count, &cnt, 8, hipMemcpyHostToDevice));
+		rc = launch_search(c, k, c->d_worklist, (uint32_t)ids.size());
+		if (rc) return rc;
+	}
+	return fail(BWB_E_OVERFLOW, "hit log kept overflowing");
+}
+
+extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
+	if (!c || !c->uploaded) return fail(BWB_E_STATE, "batch_run: no batch uploaded");
+	HIPCHK(hipSetDevice(c->device));
+	memset(&c->stats, 0, sizeof(c->stats));
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 16, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
+	if (c->n_reads == 0) { c->ran = true; return BWB_OK; }
+	HIPCHK(hipMemsetAsync(c->d_n, 0, (size_t)c->n_reads * 4, c->stream));
+	hipEvent_t t0, t1;
+	HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+	HIPCHK(hipEventRecord(t0, c->stream));
+	int rc = run_calc_d(c, nullptr, nullptr);
+	if (rc) return rc;
+	rc = launch_search(c, 0, nullptr, c->n_reads);
+	if (rc) return rc;
+	rc = rerun_out_overflow(c, 0);
+	if (rc) return rc;
+	std::vector<uint32_t> ids;
+	for (int k = 1; k <= 2; k++) {
+		rc = collect(c, ST_SCRATCH_OVF, ids);
+		if (rc) return rc;
+		if (ids.empty()) break;
+		c->stats.n_overflow_reads += ids.size();
+		rc = ensure_class(c, k);
+		if (rc) return rc;
+		rc = launch_search(c, k, c->d_worklist, (uint32_t)ids.size());
+		if (rc) return rc;
+		rc = rerun_out_overflow(c, k);
+		if (rc) return rc;
+	}
+	rc = collect(c, ST_SCRATCH_OVF, ids);
+	if (rc) return rc;
+	if (!ids.empty()) return fail(BWB_E_OVERFLOW, "a read exceeded the largest per-read scratch class");
+	HIPCHK(hipEventRecord(t1, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, t0, t1));
+	c->stats.ms_total = ms;
+	hipEventDestroy(t0); hipEventDestroy(t1);
+	unsigned long long st[16];
+	HIPCHK(hipMemcpy(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA];
+	c->stats.heap_pops = st[STAT_POPS]; c->stats.heap_pushes = st[STAT_PUSHES]; c->stats.n_alignments = st[STAT_ALNS];
+	c->ran = true;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_get_stats(bwb_hip_ctx *c, bwb_stats *out) {
+	if (!c || !out) return fail(BWB_E_ARG, "get_stats: null argument");
+	*out = c->stats;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_batch_result(bwb_hip_ctx *c, bwb_result *out) {
+	if (!c || !out) return fail(BWB_E_ARG, "batch_result: null argument");
+	if (!c->ran) return fail(BWB_E_STATE, "batch_result: batch_run has not completed");
+	HIPCHK(hipSetDevice(c->device));
+	const uint32_t n = c->n_reads;
+	std::vector<uint32_t> cnt(n ? n : 1);
+	if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+	c->h_aln_off.assign((size_t)n + 1, 0);
+	for (uint32_t i = 0; i < n; i++) c->h_aln_off[i + 1] = c->h_aln_off[i] + cnt[i];
+	const uint64_t total = c->h_aln_off[n];
+	c->h_alns.resize(total ? total : 1);
+	if (total) {
+		if (c->sorted_cap < total) {
+			hipFree(c->d_sorted); c->d_sorted = nullptr;
+			HIPCHK(hipMalloc(&c->d_sorted, total * 32));
+			c->sorted_cap = total;
+		}
+		HIPCHK(hipMemcpy(c->d_dstoff, c->h_aln_off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(k_gather, dim3((n + 31) / 32), dim3(256), 0, c->stream, c->d_log, c->d_off, c->d_n, c->d_dstoff, n, c->d_sorted);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(hipMemcpy(c->h_alns.data(), c->d_sorted, total * 32, hipMemcpyDeviceToHost));
+	}
+	out->n_reads = n;
+	out->aln_off = c->h_aln_off.data();
+	out->alns = c->h_alns.data();
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_align_batch(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                                   uint32_t n_reads, uint32_t stride, bwb_result *out) {
+	int rc = bwb_hip_batch_upload(c, p, reads_fwd, lens, n_reads, stride);
+	if (rc) return rc;
+	rc = bwb_hip_batch_run(c);
+	if (rc) return rc;
+	return bwb_hip_batch_result(c, out);
+}
+
+extern "C" int bwb_hip_calc_d(bwb_hip_ctx *c, int32_t *out_D, int32_t *out_Dseed) {
+	if (!c || !out_D || !out_Dseed) return fail(BWB_E_ARG, "calc_d: null argument");
+	if (!c->uploaded) return fail(BWB_E_STATE, "calc_d: no batch uploaded");
+	HIPCHK(hipSetDevice(c->device));
+	const size_t nD = (size_t)c->n_reads * (c->maxlen + 1) * 2, nS = (size_t)c->n_reads * (c->kp.seed_length + 1) * 2;
+	int32_t *dD = nullptr, *dS = nullptr;
+	HIPCHK(hipMalloc(&dD, (nD ? nD : 1) * 4));
+	HIPCHK(hipMalloc(&dS, (nS ? nS : 1) * 4));
+	HIPCHK(hipMemset(dD, 0, (nD ? nD : 1) * 4));
+	HIPCHK(hipMemset(dS, 0, (nS ? nS : 1) * 4));
+	memset(&c->stats, 0, sizeof(c->stats));
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 16, c->stream));
+	int rc = c->n_reads ? run_calc_d(c, dD, dS) : BWB_OK;
+	if (!rc) {
+		hipMemcpy(out_D, dD, nD * 4, hipMemcpyDeviceToHost);
+		hipMemcpy(out_Dseed, dS, nS * 4, hipMemcpyDeviceToHost);
+	}
+	hipFree(dD); hipFree(dS);
+	return rc;
+}
+
+extern "C" int bwb_hip_rank16(bwb_hip_ctx *c, const uint64_t *pos, size_t n, int inc, int exact, uint64_t *out) {
+	if (!c || (n && (!pos || !out))) return fail(BWB_E_ARG, "rank16: null argument");
+	if (n == 0) return BWB_OK;
+	for (size_t i = 0; i < n; i++)
+		if (pos[i] != ~0ull && pos[i] >= c->ix.length) return fail(BWB_E_ARG, "rank16: position out of range");
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t *dp = nullptr, *dout = nullptr;
+	HIPCHK(hipMalloc(&dp, n * 8));
+	HIPCHK(hipMalloc(&dout, n * 128));
+	HIPCHK(hipMemcpy(dp, pos, n * 8, hipMemcpyHostToDevice));
+	const unsigned grid = (unsigned)std::min<size_t>((n + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK, (size_t)c->num_cu * 8);
+	hipLaunchKernelGGL(k_rank16, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, dp, (uint64_t)n, inc, exact, dout);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(out, dout, n * 128, hipMemcpyDeviceToHost));
+	hipFree(dp); hipFree(dout);
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_rank_bench(bwb_hip_ctx *c, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum) {
+	if (!c || n == 0 || iters < 1) return fail(BWB_E_ARG, "rank_bench: bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
+	const unsigned grid = (unsigned)(c->num_cu * 8);
+	hipLaunchKernelGGL(k_rank_bench, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, seed, c->d_count); /* warm-up */
+	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
+	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	for (int i = 0; i < iters; i++)
+		hipLaunchKernelGGL(k_rank_bench, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, seed + i, c->d_count);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+	unsigned long long cs = 0;
+	HIPCHK(hipMemcpy(&cs, c->d_count, 8, hipMemcpyDeviceToHost));
+	if (ms_per_iter) *ms_per_iter = ms / iters;
+	if (checksum) *checksum = cs;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_set_sa(bwb_hip_ctx *c, const uint64_t *SA, uint64_t num_sa) {
+	if (!c || !SA || num_sa != (c->ix.length + 31) / 32) return fail(BWB_E_ARG, "set_sa: bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	hipFree(c->d_SA); c->d_SA = nullptr;
+	HIPCHK(hipMalloc(&c->d_SA, num_sa * 8));
+	HIPCHK(hipMemcpy(c->d_SA, SA, num_sa * 8, hipMemcpyHostToDevice));
+	c->num_sa = num_sa;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, uint64_t *out_pos) {
+	if (!c || (n && (!rows || !out_pos))) return fail(BWB_E_ARG, "locate: null argument");
+	if (!c->d_SA) return fail(BWB_E_STATE, "locate: sampled SA not uploaded (bwb_hip_set_sa)");
+	if (n == 0) return BWB_OK;
+	for (size_t i = 0; i < n; i++) if (rows[i] >= c->ix.length) return fail(BWB_E_ARG, "locate: row out of range");
+	HIPCHK(hipSetDevice(c->device));
+	uint64_t *dr = nullptr, *dout = nullptr;
+	HIPCHK(hipMalloc(&dr, n * 8));
+	HIPCHK(hipMalloc(&dout, n * 8));
+	HIPCHK(hipMemcpy(dr, rows, n * 8, hipMemcpyHostToDevice));
+	const unsigned grid = (unsigned)std::min<size_t>((n + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK, (size_t)c->num_cu * 8);
+	hipLaunchKernelGGL(k_locate, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, c->d_SA, c->sa0_index, dr, (uint64_t)n, dout);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpy(out_pos, dout, n * 8, hipMemcpyDeviceToHost));
+	hipFree(dr); hipFree(dout);
+	return BWB_OK;
+}

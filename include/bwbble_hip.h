@@ -1,0 +1,124 @@
+/*
+ * bwbble_hip.h - C-ABI of the MI355X (gfx950) read-alignment library, libbwbble_hip.so.
+ *
+ * This is the drop-in boundary for BWBBLE's `align` hot path.  The reference has no plugin/FFI
+ * layer; its seam is the function pair selected in align_reads (mg-aligner/align.c:72-76):
+ *
+ *     int align_reads_inexact[_parallel](bwt_t*, reads_t*, sa_intv_list_t*, aln_params_t*, char* alnFname);
+ *                                                               (mg-aligner/inexact_match.h:39-40)
+ *
+ * A maintainer adds `align_reads_inexact_gpu()` with that same signature next to them (see
+ * INTEGRATION.md and bwbble_amd/host/align_gpu.c) and it calls the entry points below.  Plain
+ * pointers and sizes only; every function returns 0 on success or a negative BWB_E_* code, never
+ * exits the process (the reference printf+exit(1)s; the host wrapper keeps that behaviour), and
+ * bwb_hip_last_error() gives the message.  Calls on distinct contexts are thread-safe (one host
+ * thread per GPU); a context must not be used from two threads at once.
+ */
+#ifndef BWBBLE_HIP_H
+#define BWBBLE_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWB_OK 0
+#define BWB_E_ARG (-1)         /* bad argument / unsupported parameter combination */
+#define BWB_E_HIP (-2)         /* HIP runtime error (no device, out of memory, launch failure) */
+#define BWB_E_OVERFLOW (-3)    /* a read exceeded the largest per-read scratch class */
+#define BWB_E_STATE (-4)       /* call order violated (e.g. run before upload) */
+
+/* mirror of aln_params_t (mg-aligner/align.h:48-79): same fields, same order, same meaning.
+ * Defaults are set_default_aln_params (mg-aligner/align.c:22-38). n_threads is ignored by the GPU. */
+typedef struct {
+	int32_t max_diff, max_gapo, max_gape, max_entries;
+	int32_t mm_score, gapo_score, gape_score;
+	int32_t seed_length, max_diff_seed, max_best, no_indel_length;
+	int32_t matched_Ncontig, use_precalc, is_multiref, n_threads;
+} bwb_params;
+
+/* One alignment hit = one aln_t (mg-aligner/align.h:81-90) in fixed 32-byte form.
+ * The edit path is all STATE_M except for <=4 gap runs (one per gap open):
+ * run = start_index_in_path | (run_length << 8) | (is_deletion << 15); unused runs are 0xFFFF. */
+typedef struct {
+	uint64_t L, U;           /* SA interval */
+	uint8_t score, num_mm, num_gapo, num_gape;
+	uint32_t aln_length;     /* 8-bit wrapped like aln_entry_t.aln_length (align.h:104) */
+	uint16_t gap_run[4];
+} bwb_aln;
+
+/* Results of one batch: read r owns alns[aln_off[r] .. aln_off[r+1]) in discovery order
+ * (== the order of alns->entries in the reference, align.c:286-297). Owned by the context;
+ * valid until the next bwb_hip_batch_* call on it. */
+typedef struct {
+	uint32_t n_reads;
+	const uint64_t *aln_off;     /* n_reads + 1 */
+	const bwb_aln *alns;
+} bwb_result;
+
+/* Work/timing counters of the last batch_run (SURVEY.md 8(d) counting rules) */
+typedef struct {
+	uint64_t visits_single;      /* rank-block visits made for the 7-code exact steps (calculate_d, exact tail) */
+	uint64_t visits_alphabet;    /* rank-block visits made for O_alphabet (2 per expansion unless special-cased) */
+	uint64_t heap_pops, heap_pushes;
+	uint64_t n_alignments;
+	uint64_t n_overflow_reads;   /* reads re-run with a larger scratch class (still on the GPU) */
+	double ms_calc_d;            /* HIP-event time of the calculate_d kernel(s) */
+	double ms_search;            /* HIP-event time of the inexact-search kernel(s), all passes */
+	double ms_total;             /* first launch .. last kernel done */
+	uint32_t launches_calc_d, launches_search;
+} bwb_stats;
+
+typedef struct bwb_hip_ctx bwb_hip_ctx;
+
+int bwb_hip_device_count(void);
+const char *bwb_hip_last_error(void);
+void bwb_default_params(bwb_params *p);                       /* align.c:22-38 */
+
+/* Creates a context on `device` and builds the device FM-index from the reference's in-memory
+ * bwt_t arrays (mg-aligner/bwt.h:19-40, file layout bwt.c:66-82):
+ *   hdr = {length, num_words, num_sa, num_occ, sa0_index}, C[17], bwt[num_words], O[num_occ*16].
+ * The index is re-laid-out on the GPU into 128-byte rank buckets; the host arrays are
+ * not referenced after return. */
+int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                       const uint64_t *O, bwb_hip_ctx **out);
+void bwb_hip_ctx_destroy(bwb_hip_ctx *ctx);
+
+/* Replaces align_reads_inexact[_parallel] for one batch (inexact_match.c:25-168): calculate_d x2 +
+ * inexact_match for n_reads reads. reads_fwd holds read->seq codes (A0 G1 C2 T3 N4, io.h:112-130),
+ * `stride` bytes per read; the reverse complement (read->rc, io.c:502-504) is formed on the GPU.
+ * == batch_upload + batch_run + batch_result. */
+int bwb_hip_align_batch(bwb_hip_ctx *ctx, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                        uint32_t n_reads, uint32_t stride, bwb_result *out);
+
+/* The same in three steps, so that a caller can time the GPU work with inputs resident in HBM. */
+int bwb_hip_batch_upload(bwb_hip_ctx *ctx, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                         uint32_t n_reads, uint32_t stride);
+int bwb_hip_batch_run(bwb_hip_ctx *ctx);                       /* kernels only; blocks until done */
+int bwb_hip_batch_result(bwb_hip_ctx *ctx, bwb_result *out);  /* D2H copy of the hits */
+int bwb_hip_get_stats(bwb_hip_ctx *ctx, bwb_stats *out);
+
+/* calculate_d for the uploaded batch (inexact_match.c:171-254): D and D_seed of every read as
+ * (num_diff, sa_intv_width) int32 pairs, out_D[n_reads][max_len+1][2], out_Dseed[n_reads][seed_length+1][2]
+ * (rows beyond a read's length are 0; D_seed rows are 0 when len <= seed_length). For parity tests. */
+int bwb_hip_calc_d(bwb_hip_ctx *ctx, int32_t *out_D, int32_t *out_Dseed);
+
+/* O_alphabet (bwt.c:374-438) for n positions: out[q][j] = C[j] + Occ(j, pos[q]) + inc with the
+ * reference's three-base-code behaviour when exact==0, or the exact count for all 15 codes
+ * (== C[j] + O(j,pos) + inc, bwt.c:348-372) when exact!=0. out[q][0] is 0. pos may be (uint64_t)-1. */
+int bwb_hip_rank16(bwb_hip_ctx *ctx, const uint64_t *pos, size_t n, int inc, int exact, uint64_t *out);
+
+/* Rank micro-benchmark: `n` pseudo-random Occ16 queries (seeded), repeated `iters` times with
+ * everything resident; returns kernel milliseconds per iteration and a checksum of the results. */
+int bwb_hip_rank_bench(bwb_hip_ctx *ctx, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum);
+
+/* SA[i] for n suffix-array rows via the invPsi walk (bwt.c:311-329); needs the sampled SA
+ * (bwt.c:80) uploaded with bwb_hip_set_sa. Used by aln2sam (align.c:760-812). */
+int bwb_hip_set_sa(bwb_hip_ctx *ctx, const uint64_t *SA, uint64_t num_sa);
+int bwb_hip_locate(bwb_hip_ctx *ctx, const uint64_t *rows, size_t n, uint64_t *out_pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,99 @@
+"""GPU parity tests: the HIP path (through the C-ABI, bwbble_amd ctypes mirror) against the golden vectors of
+the real reference and against the CPU oracle on the same seeded inputs.  Bit-exact (integer work)."""
+import os
+
+import numpy as np
+import pytest
+
+import bwbble_amd as bw
+from golden.make_golden import ALIGN_CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy_ctx(golden, built):
+    ctx = bw.Context(os.path.join(golden, "toy.fa.bwt"))
+    yield ctx
+    ctx.close()
+
+
+def test_rank16_matches_reference_O_alphabet(toy_ctx, golden):
+    pos = np.load(os.path.join(golden, "rank_pos.npy"))
+    for inc in (0, 1):
+        ref = np.load(os.path.join(golden, f"rank_O_alphabet_inc{inc}.npy"))
+        got = toy_ctx.rank16(pos, inc=inc, exact=False)
+        assert np.array_equal(got[:, 1:], ref[:, 1:])
+
+
+def test_rank16_exact_matches_reference_O(toy_ctx, golden):
+    pos = np.load(os.path.join(golden, "rank_pos.npy"))
+    ref = np.load(os.path.join(golden, "rank_O_single.npy"))
+    got = toy_ctx.rank16(pos, inc=0, exact=True)
+    Cj = toy_ctx.bwt.C[:16].astype(np.uint64)
+    assert np.array_equal(got[:, 1:], ref[:, 1:] + Cj[None, 1:])
+
+
+@pytest.mark.parametrize("tag", ["toy", "ragged"])
+def test_calculate_d_matches_reference(toy_ctx, golden, tag):
+    reads = bw.read_fastq(os.path.join(golden, f"{tag}.fq"))
+    seqs, lens = bw.encode_reads(reads)
+    p = bw.params()
+    D, Ds = toy_ctx.calc_d(p, seqs, lens)
+    vec = np.load(os.path.join(golden, f"dvec_{tag}.npy"))
+    off = 0
+    for i in range(len(reads)):
+        ln, seed = int(vec[off]), int(vec[off + 1]); off += 2
+        rD = vec[off:off + 2 * (ln + 1)].reshape(ln + 1, 2); off += 2 * (ln + 1)
+        rS = vec[off:off + 2 * (seed + 1)].reshape(seed + 1, 2); off += 2 * (seed + 1)
+        assert np.array_equal(D[i, :ln + 1], rD), f"D mismatch read {i}"
+        if ln > seed:
+            assert np.array_equal(Ds[i], rS), f"D_seed mismatch read {i}"
+
+
+@pytest.mark.parametrize("name", sorted(ALIGN_CONFIGS))
+def test_aln_bytes_match_reference_toy(toy_ctx, golden, name):
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "toy.fq")))
+    off, alns = toy_ctx.align(bw.params(ALIGN_CONFIGS[name]), seqs, lens)
+    assert bw.aln_bytes(off, alns) == open(os.path.join(golden, f"toy_{name}.aln"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap"])
+def test_aln_bytes_match_reference_ragged(toy_ctx, golden, name):
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "ragged.fq")))
+    off, alns = toy_ctx.align(bw.params(ALIGN_CONFIGS[name]), seqs, lens)
+    assert bw.aln_bytes(off, alns) == open(os.path.join(golden, f"ragged_{name}.aln"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["n0", "n3"])
+def test_work_counters_match_oracle(toy_ctx, oracle, golden, name):
+    """The visit counts that feed roofline.achieved are the SURVEY 8(d) algorithmic counts."""
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "toy.fq")))
+    toy_ctx.align(bw.params(ALIGN_CONFIGS[name]), seqs, lens)
+    st = toy_ctx.stats()
+    idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"))
+    _, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(ALIGN_CONFIGS[name]))
+    assert st.visits_single == ost.visits_single
+    assert st.visits_alphabet == ost.visits_alphabet
+    assert st.heap_pops == ost.heap_pops
+    assert st.heap_pushes == ost.heap_pushes
+    assert st.n_alignments == ost.n_alignments
+
+
+def test_empty_and_degenerate_batches(toy_ctx):
+    p = bw.params(["-n", "2"])
+    off, alns = toy_ctx.align(p, np.zeros((0, 1), dtype=np.uint8), np.zeros(0, dtype=np.uint16))
+    assert len(off) == 1 and len(alns) == 0
+    # all-N read, and a read with more N's than max_diff: empty records (inexact_match.c:260-266)
+    seqs = np.full((2, 40), 4, dtype=np.uint8)
+    seqs[1, :37] = 0
+    off, alns = toy_ctx.align(p, seqs, np.array([40, 40], dtype=np.uint16))
+    assert list(off) == [0, 0, 0]
+
+
+def test_unsupported_parameters_fail_loudly(toy_ctx):
+    seqs = np.zeros((1, 40), dtype=np.uint8)
+    lens = np.array([40], dtype=np.uint16)
+    for flags in (["-S"], ["-P"], ["-o", "9"]):
+        with pytest.raises(bw.BwbError):
+            toy_ctx.align(bw.params(flags), seqs, lens)
