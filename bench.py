@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark: 100 bp reads aligned per second on a synthetic IUPAC multi-genome, MI355X.
+
+One "step" = one pass of the hot path (k_calc_d + k_search, all scratch-class passes) over one batch of
+synthetic reads that is already resident in HBM (bwb_hip_batch_upload done before the timed region).
+Multi-GPU: one process per GPU, FM-index replicated, reads sharded (each rank aligns its own batch),
+no data-path collective; weak scaling.  See DESIGN.md "Measurement".
+
+  python bench.py [--gpus N --steps K --warmup W] [--genome-mb 48 --reads 1000000 --ndiff 3]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+ALG_BYTES_PER_VISIT = 192  # one reference checkpoint row (128 B) + one packed BWT block (64 B)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("BWB_BENCH_GENOME_MB", 48)),
+                    help="forward characters of the synthetic genome, in millions (48 = chr21 scale, config C2)")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BWB_BENCH_READS", 1000000)), help="reads per GPU per step")
+    ap.add_argument("--ndiff", type=int, default=int(os.environ.get("BWB_BENCH_NDIFF", 3)), help="-n (the reference default is 0; see DESIGN.md)")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BWB_BENCH_CPU_SAMPLE", 0)), help="reads in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--workdir", default=os.environ.get("BWB_BENCH_DIR", "/tmp/bwb_bench"))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    import torch  # plumbing only (synchronize, barrier, max-over-ranks); imported first so that one HIP runtime is shared
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import numpy as np
+    import bwbble_amd as bw
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- workload: synthetic genome + index (built once, by rank 0, with the product's own indexer) ----------
+    n_fwd = int(a.genome_mb * 1e6)
+    os.makedirs(a.workdir, exist_ok=True)
+    fa = os.path.join(a.workdir, f"genome_{n_fwd}.fa")
+    if rank == 0:
+        bw.build()
+        if not os.path.exists(fa + ".bwt"):
+            n_rec = 1 if n_fwd <= 60_000_000 else 24
+            subprocess.run([bw.SYNTH_BIN, "genome", fa, str(n_fwd), str(n_rec), str(max(4, n_fwd // 2400)), "21"], check=True)
+            subprocess.run([bw.HOST_BIN, "index", fa], check=True, stdout=subprocess.DEVNULL)
+    barrier()
+    fq = os.path.join(a.workdir, f"reads_{n_fwd}_{a.reads}_{a.read_len}_r{rank}.fq")
+    if not os.path.exists(fq):
+        subprocess.run([bw.SYNTH_BIN, "reads", fa, fq, str(a.reads), str(a.read_len), str(1000 + rank), "1.0", "0.1", "0.0"], check=True)
+    seqs, lens = bw.encode_reads(bw.read_fastq(fq))
+    flags = ["-n", str(a.ndiff)]
+    p = bw.params(flags)
+    bwt = bw.BwtFile(fa + ".bwt")
+    ctx = bw.Context(bwt, device=local_rank)
+    ctx.upload(p, seqs, lens)  # reads resident in HBM before any timed region
+
+    for _ in range(a.warmup):
+        ctx.run()
+    barrier()
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    t0 = time.perf_counter()
+    kern_ms = visits = 0.0
+    for _ in range(a.steps):
+        ctx.run()  # blocks until the last kernel of the step has finished (hipStreamSynchronize inside)
+        st = ctx.stats()
+        kern_ms += st.ms_calc_d + st.ms_search  # HIP events recorded on the library's own stream
+        visits += st.visits_single + st.visits_alphabet
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, kern_ms, visits], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, kern_ms, visits = float(tmax[0]), float(tmax[1]), float(tsum[2]) / world
+    st = ctx.stats()
+    off, alns = ctx.result()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    total_reads = a.reads * world * a.steps
+    value = total_reads / dt
+    # roofline of the dominant kernels (k_calc_d + k_search are one pass over the same rank buckets): algorithmic
+    # bytes = 192 B x rank-block visits (counted in-kernel with the SURVEY 8(d) rule, equal to the oracle's count)
+    alg_bytes_per_step = visits / a.steps * ALG_BYTES_PER_VISIT
+    achieved = alg_bytes_per_step / (kern_ms / a.steps * 1e-3) / 1e9
+    out = {
+        "metric": "100bp reads aligned/sec (inexact BWT backward search, IUPAC FM-index)", "value": round(value, 1), "unit": "reads/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"C2 chr21-scale synthetic multi-genome: {n_fwd} fwd chars (BWT length {bwt.length}), "
+                               f"{a.reads} x {a.read_len} bp reads per GPU, align -n {a.ndiff} (other params default)",
+                   "reads_per_gpu": a.reads, "read_len": a.read_len, "max_diff": a.ndiff, "bwt_length": int(bwt.length),
+                   "sharding": f"reads x{world}, index replicated"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "k_calc_d+k_search", "visits_per_step": int(visits / a.steps),
+                     "kernel_ms_per_step": round(kern_ms / a.steps, 3)},
+        "hits": int(off[-1]), "rerun_reads": int(st.n_overflow_reads),
+    }
+    # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only) --------------------------------
+    if world == 1:
+        out["cpu_baseline"] = cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw):
+    """Times the REAL reference (oracle/_ref/bwbble, OpenMP, -t all cores) when its prebuilt binary is present, else the
+    CPU oracle port, on the first `sample` reads; also re-checks parity of that sample against the GPU result."""
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    # ~10-30 s of CPU work: the reference does ~250 (n=3) .. 1350 (n=0) reads/s/core at chr21 scale
+    per_core = {0: 1300.0, 1: 900.0, 2: 500.0, 3: 240.0}.get(a.ndiff, 150.0)
+    sample = a.cpu_sample or int(min(a.reads, max(2000, per_core * cores * 12)))
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "bwbble")
+    orc = oracle_lib.load()
+    res = {"cores": cores, "unit": "reads/s"}
+    sfq = fq + f".sample{sample}"
+    with open(fq) as f, open(sfq, "w") as g:
+        for i, line in enumerate(f):
+            if i >= 4 * sample:
+                break
+            g.write(line)
+    if os.path.exists(ref_bin):
+        # the reference times with clock() (CPU time summed over threads), so take wall time of two runs and subtract
+        # the fixed index/FASTQ load cost measured with a 1-read FASTQ
+        one = fq + ".one"
+        with open(fq) as f, open(one, "w") as g:
+            for i, line in enumerate(f):
+                if i >= 4:
+                    break
+                g.write(line)
+        def t_run(path, out):
+            t = time.perf_counter()
+            subprocess.run([ref_bin, "align"] + flags + ["-t", str(cores), fa, path, out], check=True, stdout=subprocess.DEVNULL)
+            return time.perf_counter() - t
+        t_load = t_run(one, sfq + ".one.aln")
+        t_all = t_run(sfq, sfq + ".aln")
+        sec = max(t_all - t_load, 1e-6)
+        ref_bytes = open(sfq + ".aln", "rb").read()
+        res.update({"value": round(sample / sec, 1), "kind": "reference",
+                    "sample": f"first {sample} reads of the same FASTQ, oracle/_ref/bwbble align -t {cores}; wall {t_all:.2f}s minus {t_load:.2f}s load"})
+    else:
+        idx = orc.load_index(fa + ".bwt")
+        ref_bytes, _, sec = orc.align_encoded(idx, seqs[:sample], lens[:sample], orc.params(flags + ["-t", str(cores)]))
+        res.update({"value": round(sample / sec, 1), "kind": "port",
+                    "sample": f"first {sample} reads, oracle/libbwb_oracle.so with {cores} OpenMP threads, align loop only"})
+    res["parity_on_sample"] = bool(bw.aln_bytes(off[:sample + 1], alns[:int(off[sample])]) == ref_bytes)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+/* aln_io.c - .aln records, byte-compatible with alns2alnf_bin / alnsf2alns_bin (mg-aligner/align.c:345-382,
+ * 430-483): i32 num_entries, then per entry i32 score, u64 L, u64 U, i32 num_mm, num_gapo,
+ * num_gape, aln_length, i32 state_pairs, i32 pair[] with pair = state | (count << 2), path walked from index
+ * aln_length-1 down to 0. */
+#include <stdlib.h>
+#include <string.h>
+#include "bwb_host.h"
+
+/* the edit path is all STATE_M(0) except for the gap runs recorded by the kernel */
+int aln_path_bytes(const bwb_aln *a, unsigned char *path) {
+	memset(path, 0, 272);
+	for (int k = 0; k < 4; k++) {
+		const unsigned run = a->gap_run[k];
+		if (run == 0xFFFFu) continue;
+		const unsigned start = run & 0xFF, len = (run >> 8) & 0x7F, st = (run >> 15) ? 2 : 1; /* STATE_D : STATE_I */
+		for (unsigned q = 0; q < len && start + q < 272; q++) path[start + q] = (unsigned char)st;
+	}
+	return (int)a->aln_length;
+}
+
+void alns2alnf_bin(const bwb_aln *alns, uint64_t n, FILE *f) {
+	int32_t buf[8 + 272];
+	int32_t ne = (int32_t)n;
+	fwrite(&ne, 4, 1, f);
+	unsigned char path[272];
+	for (uint64_t i = 0; i < n; i++) {
+		const bwb_aln *a = &alns[i];
+		const int alen = aln_path_bytes(a, path);
+		int32_t score = a->score, v[4] = { a->num_mm, a->num_gapo, a->num_gape, alen };
+		fwrite(&score, 4, 1, f);
+		fwrite(&a->L, 8, 1, f);
+		fwrite(&a->U, 8, 1, f);
+		fwrite(v, 4, 4, f);
+		int32_t pairs = 0;
+		if (alen > 0) {
+			int state = path[alen - 1];
+			uint16_t counter = 1;
+			pairs = 1;
+			for (int j = alen - 2; j >= 0; j--) {
+				if (state == path[j]) counter++;
+				else { buf[pairs] = state | (counter << 2); state = path[j]; counter = 1; pairs++; }
+			}
+			buf[pairs] = state | (counter << 2);
+			buf[0] = pairs;
+			fwrite(buf, 4, (size_t)pairs + 1, f);
+		} else fwrite(&pairs, 4, 1, f);
+	}
+}
+
+alns_batch_t *alnsf2alns_bin(const char *alnFname) {
+	FILE *f = fopen(alnFname, "rb");
+	if (!f) bwb_die("alnsf2alns: Cannot open ALN file: %s!", alnFname);
+	alns_batch_t *b = (alns_batch_t *)calloc(1, sizeof(*b));
+	size_t rcap = 1u << 16, acap = 1u << 16, na = 0;
+	b->aln_off = (uint64_t *)malloc((rcap + 1) * 8);
+	b->alns = (bwb_aln *)malloc(acap * sizeof(bwb_aln));
+	b->aln_off[0] = 0;
+	int32_t ne;
+	while (fread(&ne, 4, 1, f) == 1) {
+		if (b->n_reads == rcap) { rcap *= 2; b->aln_off = (uint64_t *)realloc(b->aln_off, (rcap + 1) * 8); }
+		for (int i = 0; i < ne; i++) {
+			if (na == acap) { acap *= 2; b->alns = (bwb_aln *)realloc(b->alns, acap * sizeof(bwb_aln)); }
+			bwb_aln *a = &b->alns[na++];
+			int32_t score, v[4], pairs;
+			if (fread(&score, 4, 1, f) < 1 || fread(&a->L, 8, 1, f) < 1 || fread(&a->U, 8, 1, f) < 1 || fread(v, 4, 4, f) < 4 || fread(&pairs, 4, 1, f) < 1)
+				bwb_die("alnsf2alns: Could not read ALN file: %s!", alnFname);
+			a->score = (uint8_t)score; a->num_mm = (uint8_t)v[0]; a->num_gapo = (uint8_t)v[1]; a->num_gape = (uint8_t)v[2];
+			a->aln_length = (uint32_t)v[3];
+			for (int k = 0; k < 4; k++) a->gap_run[k] = 0xFFFF;
+			/* The reference loader fills aln_path in PAIR order (align.c:466-476), i.e. the loaded path is the
+			 * align-time path reversed (pairs were written from index aln_length-1 down to 0, align.c:363-373);
+			 * eval_aln / print_aln2sam work on that orientation, so the gap runs are rebuilt the same way. */
+			int32_t *pp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(pairs > 0 ? pairs : 1));
+			if (pairs > 0 && fread(pp, 4, (size_t)pairs, f) < (size_t)pairs) bwb_die("alnsf2alns: Could not read ALN file: %s!", alnFname);
+			int pos = 0, nrun = 0;
+			for (int k = 0; k < pairs; k++) {
+				const int st = pp[k] & 3, cnt = pp[k] >> 2;
+				if (st != 0 && nrun < 4) a->gap_run[nrun++] = (uint16_t)((pos & 0xFF) | ((cnt & 0x7F) << 8) | (st == 2 ? 0x8000 : 0));
+				pos += cnt;
+			}
+			free(pp);
+		}
+		b->n_reads++;
+		b->aln_off[b->n_reads] = na;
+	}
+	fclose(f);
+	return b;
+}
+
+void free_alns_batch(alns_batch_t *b) {
+	if (!b) return;
+	free(b->aln_off); free(b->alns); free(b);
+}

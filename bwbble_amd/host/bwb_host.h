@@ -1,0 +1,93 @@
+/*
+ * bwb_host.h - host side (C) of the MI355X BWBBLE aligner: the reference's own data types and
+ * entry points for the `index | align | aln2sam` path, re-implemented from scratch, with the
+ * alignment loop handed to libbwbble_hip.so through include/bwbble_hip.h.
+ *
+ * Names follow the reference (mg-aligner/{bwt.h,io.h,align.h,inexact_match.h}) so that the seam is
+ * obvious: align_reads_inexact_gpu() has the signature of align_reads_inexact_parallel()
+ * (inexact_match.h:40) and is selected next to it in align_reads() (align.c:72-76).
+ */
+#ifndef BWB_HOST_H
+#define BWB_HOST_H
+#include <stdint.h>
+#include <stdio.h>
+#include "bwbble_hip.h"
+
+typedef uint64_t bwtint_t;
+
+#define OCC_INTERVAL 128        /* bwt.h:14 */
+#define SA_INTERVAL 32          /* bwt.h:16 */
+#define ALPHABET_SIZE 16        /* io.h:27 */
+#define MAX_SEQ_NAME_LEN 256    /* io.h:10 */
+
+/* bwt_t (bwt.h:19-40) minus the 64 K-entry LUT (popcounts are used instead) */
+typedef struct {
+	bwtint_t length, num_words;
+	uint32_t *bwt;
+	bwtint_t C[ALPHABET_SIZE + 1];
+	bwtint_t *O;
+	bwtint_t num_occ;
+	bwtint_t *SA;
+	bwtint_t num_sa;
+	bwtint_t sa0_index;
+} bwt_t;
+
+/* reads_t/read_t (io.h:151-194) in structure-of-arrays form: codes are read->seq (A0 G1 C2 T3 N4) */
+typedef struct {
+	unsigned int count, max_len;
+	uint32_t stride;            /* bytes per read in seq */
+	uint8_t *seq;               /* [count][stride] */
+	uint16_t *len;
+	char *raw;                  /* the FASTQ text; names and qualities point into it */
+	size_t *name_off, *qual_off;
+	uint16_t *name_len;
+} reads_t;
+
+typedef struct {                /* seq_annotation_t / fasta_annotations_t (io.h:196-207) */
+	char name[MAX_SEQ_NAME_LEN + 1];
+	bwtint_t start_index, end_index;
+} seq_annotation_t;
+typedef struct { int num_seq; seq_annotation_t *seq_anns; } fasta_annotations_t;
+
+typedef bwb_params aln_params_t; /* align.h:48-79 */
+
+/* alignments of a batch as loaded from / written to .aln (align.c:345-382,430-483) */
+typedef struct {
+	size_t n_reads;
+	uint64_t *aln_off;          /* n_reads + 1 */
+	bwb_aln *alns;
+} alns_batch_t;
+
+void bwb_die(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)));
+
+/* bwt_io.c */
+void store_bwt(const bwt_t *BWT, const char *bwtFname);                /* bwt.c:66-82 */
+bwt_t *load_bwt(const char *bwtFname, int loadSA);                     /* bwt.c:90-125 */
+void free_bwt(bwt_t *BWT);
+
+/* index.c */
+int index_bwt(const char *fastaFname, const char *extSAFname);         /* bwt.c:29-63 */
+void fasta2ref(const char *fastaFname, const char *refFname, const char *annFname, unsigned char **seq, bwtint_t *totalSeqLen); /* io.c:190-321 */
+bwt_t *construct_bwt(unsigned char *seq, bwtint_t length);             /* bwt.c:161-218 */
+fasta_annotations_t *annf2ann(const char *annFname);                   /* io.c:324-349 */
+void free_ann(fasta_annotations_t *a);
+
+/* reads.c */
+reads_t *fastq2reads(const char *readsFname);                          /* io.c:410-515 */
+void free_reads(reads_t *reads);
+
+/* aln_io.c */
+void alns2alnf_bin(const bwb_aln *alns, uint64_t n, FILE *alnFile);    /* align.c:345-382, one read */
+alns_batch_t *alnsf2alns_bin(const char *alnFname);                    /* align.c:430-483 */
+void free_alns_batch(alns_batch_t *b);
+int aln_path_bytes(const bwb_aln *a, unsigned char *path /* >= 272 bytes */); /* edit path from the gap runs; returns aln_length */
+
+/* align_gpu.c */
+void set_default_aln_params(aln_params_t *params);                     /* align.c:22-38 */
+int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_t *params, int n_gpus); /* align.c:40-87 */
+int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_intervals, aln_params_t *params, char *alnFname, int n_gpus);
+
+/* sam.c */
+void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFname, int is_multiref, int max_diff, int n_gpus); /* align.c:494-556 */
+
+#endif

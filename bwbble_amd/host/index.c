@@ -1,0 +1,287 @@
+/*
+ * index.c - `bwbble index`: FASTA -> .ref/.ann/.bwt, byte-compatible with the reference
+ * (mg-aligner/bwt.c:29-63,161-218,266-291; io.c:190-321).
+ *
+ * Host plumbing, not the accelerated path.  The reference builds the suffix array with a vendored
+ * sais-lite (is.c); this file uses its own construction: suffixes are distributed by their first
+ * five characters (20-bit radix, counting sort) and every bucket is refined by sorting 16-character
+ * super-characters (64-bit keys) recursively, buckets in parallel (OpenMP).  The resulting order is
+ * the plain suffix order with the end of the text smaller than every character, which is what
+ * is_bwt() produces (is.c:197-243), so the files come out identical (tests/test_host_index.py).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "bwb_host.h"
+
+/* io.h:32 and io.h:132-149 */
+static const unsigned char iupacCompl[16] = { 0, 15, 8, 7, 4, 11, 12, 3, 2, 13, 10, 5, 6, 9, 14, 1 };
+static unsigned char nt16(int c) {
+	switch (c) {
+	case '$': return 0;
+	case 'T': return 1; case 'K': return 2; case 'G': return 3; case 'S': return 4; case 'B': return 5; case 'Y': return 6;
+	case 'C': return 7; case 'M': return 8; case 'H': return 9; case 'N': return 10; case 'V': return 11; case 'R': return 12;
+	case 'D': return 13; case 'W': return 14; case 'A': return 15;
+	default: return 10; /* anything else is N */
+	}
+}
+
+static double wall(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+/* io.c:190-321 */
+void fasta2ref(const char *fastaFname, const char *refFname, const char *annFname, unsigned char **seq_out, bwtint_t *totalSeqLen) {
+	FILE *f = fopen(fastaFname, "r");
+	if (!f) bwb_die("fasta2ref: Cannot open FASTA file: %s!", fastaFname);
+	fseek(f, 0, SEEK_END);
+	long sz = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	char *raw = (char *)malloc((size_t)sz + 1);
+	if (!raw || fread(raw, 1, (size_t)sz, f) != (size_t)sz) bwb_die("fasta2ref: Cannot read FASTA file: %s!", fastaFname);
+	fclose(f);
+	if (sz == 0 || raw[0] != '>') bwb_die("Error: File %s not in FASTA format", fastaFname);
+	FILE *annFile = fopen(annFname, "wb");
+	if (!annFile) bwb_die("fasta2ref: Cannot open .ann file: %s!", annFname);
+
+	unsigned char *seq = (unsigned char *)malloc(2 * (size_t)sz + 16);
+	if (!seq) bwb_die("fasta2ref: Could not allocate memory for the input sequence");
+	bwtint_t seqLen = 0;
+	int nann = 0, cap = 256;
+	seq_annotation_t *anns = (seq_annotation_t *)malloc(sizeof(seq_annotation_t) * (size_t)cap);
+	long p = 1; /* past the first '>' */
+	while (p <= sz) {
+		if (nann == cap) { cap *= 2; anns = (seq_annotation_t *)realloc(anns, sizeof(seq_annotation_t) * (size_t)cap); }
+		seq_annotation_t *a = &anns[nann];
+		int nl = 0;
+		while (p < sz && raw[p] != '\n' && nl < MAX_SEQ_NAME_LEN) a->name[nl++] = raw[p++]; /* io.c:237-241 */
+		a->name[nl] = 0;
+		while (p < sz && raw[p] != '\n') p++;
+		if (p >= sz) bwb_die("Error: File %s not in FASTA format", fastaFname);      /* io.c:246 */
+		bwtint_t sub = 0;
+		p++;
+		while (p < sz && raw[p] != '>') {                                             /* io.c:250-273 */
+			int c = raw[p++];
+			if (c == '\n') continue;
+			if (c >= 'a' && c <= 'z') c += 'A' - 'a';
+			seq[seqLen++] = nt16(c);
+			sub++;
+		}
+		seq[seqLen++] = 0; /* '$' separator after every record, io.c:276 */
+		sub++;
+		printf("Done reading a subsequence of size %llu from FASTA\n", (unsigned long long)sub);
+		a->start_index = seqLen - sub;
+		a->end_index = seqLen - 1;
+		nann++;
+		if (p >= sz) break;
+		p++; /* skip '>' */
+	}
+	printf("Done reading FASTA file. Total sequence length read = %llu\n", (unsigned long long)seqLen);
+	fprintf(annFile, "%llu\t%d\n", (unsigned long long)seqLen, nann);                 /* io.c:292-296 */
+	for (int i = 0; i < nann; i++)
+		fprintf(annFile, "%s\t%llu\t%llu\n", anns[i].name, (unsigned long long)anns[i].start_index, (unsigned long long)anns[i].end_index);
+	fclose(annFile);
+	for (bwtint_t i = 0; i < seqLen; i++) seq[2 * seqLen - i - 1] = iupacCompl[seq[i]]; /* io.c:304-306 */
+	*totalSeqLen = 2 * seqLen;
+	if (refFname) {
+		FILE *rf = fopen(refFname, "wb");
+		if (!rf) bwb_die("fasta2ref: Cannot open .ref file: %s!", refFname);
+		fwrite(seq, 1, 2 * seqLen, rf);                                               /* io.c:269,311: raw codes, fwd then revcomp */
+		fclose(rf);
+		printf("Wrote %llu chars to ref file\n", (unsigned long long)(2 * seqLen));
+	}
+	free(anns);
+	free(raw);
+	*seq_out = seq;
+}
+
+fasta_annotations_t *annf2ann(const char *annFname) { /* io.c:324-349 */
+	FILE *f = fopen(annFname, "r");
+	if (!f) bwb_die("annf2ann: Cannot open ANN file: %s!", annFname);
+	fasta_annotations_t *a = (fasta_annotations_t *)calloc(1, sizeof(*a));
+	unsigned long long tot;
+	if (fscanf(f, "%llu\t%d\n", &tot, &a->num_seq) != 2) bwb_die("annf2ann: Could not parse ANN file: %s!", annFname);
+	a->seq_anns = (seq_annotation_t *)calloc((size_t)a->num_seq, sizeof(seq_annotation_t));
+	for (int i = 0; i < a->num_seq; i++) {
+		unsigned long long s, e;
+		if (fscanf(f, "%256[^\n\t]\t%llu\t%llu\n", a->seq_anns[i].name, &s, &e) < 3) bwb_die("annf2ann: Could not parse ANN file: %s!", annFname);
+		a->seq_anns[i].start_index = s; a->seq_anns[i].end_index = e;
+	}
+	fclose(f);
+	return a;
+}
+void free_ann(fasta_annotations_t *a) { if (a) { free(a->seq_anns); free(a); } }
+
+/* ---------------------------------------------------------------------------------------------
+ * Suffix sorting
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t key; uint64_t idx; } kv_t;
+
+/* 16 characters starting at position i as one big-endian 64-bit key; pk = nibble-packed text
+ * (char 2k in the high nibble of byte k) padded with zero bytes. */
+static inline uint64_t key16(const unsigned char *pk, uint64_t i) {
+	uint64_t w;
+	memcpy(&w, pk + (i >> 1), 8);
+	w = __builtin_bswap64(w);
+	if (i & 1) w = (w << 4) | (pk[(i >> 1) + 8] >> 4);
+	return w;
+}
+
+static void kv_insertion(kv_t *a, long n) {
+	for (long i = 1; i < n; i++) {
+		kv_t v = a[i];
+		long j = i - 1;
+		while (j >= 0 && a[j].key > v.key) { a[j + 1] = a[j]; j--; }
+		a[j + 1] = v;
+	}
+}
+static void kv_sort(kv_t *a, long n) { /* quicksort on key, median of three, explicit stack */
+	long stk[128][2];
+	int sp = 0;
+	stk[sp][0] = 0; stk[sp][1] = n - 1; sp++;
+	while (sp) {
+		sp--;
+		long lo = stk[sp][0], hi = stk[sp][1];
+		while (hi - lo > 24) {
+			long mid = lo + (hi - lo) / 2;
+			uint64_t x = a[lo].key, y = a[mid].key, z = a[hi].key;
+			uint64_t pv = (x < y) ? ((y < z) ? y : (x < z ? z : x)) : ((x < z) ? x : (y < z ? z : y));
+			long i = lo, j = hi;
+			while (i <= j) {
+				while (a[i].key < pv) i++;
+				while (a[j].key > pv) j--;
+				if (i <= j) { kv_t t = a[i]; a[i] = a[j]; a[j] = t; i++; j--; }
+			}
+			if (j - lo < hi - i) { if (i < hi) { stk[sp][0] = i; stk[sp][1] = hi; sp++; } hi = j; }
+			else { if (lo < j) { stk[sp][0] = lo; stk[sp][1] = j; sp++; } lo = i; }
+		}
+		kv_insertion(a + lo, hi - lo + 1);
+	}
+}
+
+/* sorts the suffixes sa[0..m) that agree on their first `depth` characters */
+static void refine(const unsigned char *pk, uint64_t n, uint64_t *sa, long m, uint64_t depth, kv_t *tmp) {
+	while (m > 1) {
+		/* suffixes that end exactly here are the smallest of the group; among them the shorter (= larger
+		 * start) comes first */
+		long ne = 0;
+		for (long i = 0; i < m; i++)
+			if (sa[i] + depth >= n) { uint64_t t = sa[i]; sa[i] = sa[ne]; sa[ne] = t; ne++; }
+		for (long i = 1; i < ne; i++) { uint64_t v = sa[i]; long j = i - 1; while (j >= 0 && sa[j] < v) { sa[j + 1] = sa[j]; j--; } sa[j + 1] = v; }
+		sa += ne; m -= ne;
+		if (m <= 1) return;
+		for (long i = 0; i < m; i++) { tmp[i].key = key16(pk, sa[i] + depth); tmp[i].idx = sa[i]; }
+		kv_sort(tmp, m);
+		for (long i = 0; i < m; i++) sa[i] = tmp[i].idx;
+		/* recurse into groups of equal keys; the last (or only) group is handled by the loop */
+		long g0 = 0, big0 = -1, bigm = 0;
+		for (long i = 1; i <= m; i++) {
+			if (i == m || tmp[i].key != tmp[g0].key) {
+				const long gm = i - g0;
+				if (gm > 1) {
+					if (big0 < 0) { big0 = g0; bigm = gm; }
+					else {
+						/* keep the larger group for the loop, recurse into the smaller with its own buffer */
+						long r0 = g0, rm = gm;
+						if (gm > bigm) { r0 = big0; rm = bigm; big0 = g0; bigm = gm; }
+						kv_t *t2 = (kv_t *)malloc(sizeof(kv_t) * (size_t)rm);
+						refine(pk, n, sa + r0, rm, depth + 16, t2);
+						free(t2);
+					}
+				}
+				g0 = i;
+			}
+		}
+		if (big0 < 0) return;
+		sa += big0; m = bigm; depth += 16;
+	}
+}
+
+/* SA of seq[0..n) in the reference's row convention: SA[0] = n (empty suffix), is.c:197-206 */
+static uint64_t *build_sa(const unsigned char *seq, uint64_t n) {
+	uint64_t *SA = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1));
+	unsigned char *pk = (unsigned char *)calloc((n >> 1) + 64, 1);
+	if (!SA || !pk) bwb_die("is_bwt: Could not allocate memory for the BWT index construction, alloc'ing %llu Mb", (unsigned long long)((n + 1) * 8 / 1024 / 1024));
+	for (uint64_t i = 0; i < n; i++) pk[i >> 1] |= (unsigned char)(seq[i] << ((i & 1) ? 0 : 4));
+	SA[0] = n;
+	const int RB = 20; /* 5 characters */
+	const uint64_t NB = 1ull << RB;
+	uint64_t *cnt = (uint64_t *)calloc(NB + 1, sizeof(uint64_t));
+	/* bucket id = first 5 characters (zero padded); suffixes shorter than 5 sort first inside their bucket via refine() */
+#define BKT(i) (key16(pk, (i)) >> (64 - RB))
+	for (uint64_t i = 0; i < n; i++) cnt[BKT(i) + 1]++;
+	for (uint64_t b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
+	uint64_t *fill = (uint64_t *)malloc(sizeof(uint64_t) * NB);
+	memcpy(fill, cnt, sizeof(uint64_t) * NB);
+	uint64_t *S = SA + 1;
+	for (uint64_t i = 0; i < n; i++) S[fill[BKT(i)]++] = i;
+	free(fill);
+	uint64_t maxb = 0;
+	for (uint64_t b = 0; b < NB; b++) if (cnt[b + 1] - cnt[b] > maxb) maxb = cnt[b + 1] - cnt[b];
+#pragma omp parallel
+	{
+		kv_t *tmp = (kv_t *)malloc(sizeof(kv_t) * (size_t)(maxb ? maxb : 1));
+#pragma omp for schedule(dynamic, 16)
+		for (long b = 0; b < (long)NB; b++) {
+			const long m = (long)(cnt[b + 1] - cnt[b]);
+			if (m > 1) refine(pk, n, S + cnt[b], m, 0, tmp);
+		}
+		free(tmp);
+	}
+#undef BKT
+	free(cnt);
+	free(pk);
+	return SA;
+}
+
+/* bwt.c:161-218 (is_bwt is.c:214-243, pack_word io.c:590-609, compute_C bwt.c:266-277, compute_O bwt.c:280-291) */
+bwt_t *construct_bwt(unsigned char *ref, bwtint_t length) {
+	bwt_t *B = (bwt_t *)calloc(1, sizeof(bwt_t));
+	B->length = length + 1;
+	B->num_sa = (bwtint_t)ceil(((double)B->length) / SA_INTERVAL);
+	B->SA = (bwtint_t *)calloc(B->num_sa, sizeof(bwtint_t));
+	double t = wall();
+	uint64_t *SA = build_sa(ref, length);
+	printf("Suffix sort time: %.2f sec\n", wall() - t);
+	unsigned char *bw = (unsigned char *)malloc(B->length);
+	for (bwtint_t i = 0; i <= length; i++) {
+		if (i % SA_INTERVAL == 0) B->SA[i / SA_INTERVAL] = SA[i];
+		if (SA[i] == 0) { B->sa0_index = i; bw[i] = 0; }
+		else bw[i] = ref[SA[i] - 1];
+	}
+	free(SA);
+	B->num_words = (bwtint_t)ceil(((double)B->length) / 8);
+	B->bwt = (uint32_t *)calloc(B->num_words, sizeof(uint32_t));
+	B->num_occ = (bwtint_t)ceil(((double)B->length) / OCC_INTERVAL);
+	B->O = (bwtint_t *)calloc(B->num_occ * ALPHABET_SIZE, sizeof(bwtint_t));
+	if (!B->bwt || !B->O) bwb_die("construct_bwt: Could not allocate memory for the BWT index");
+	for (bwtint_t i = 0; i < B->length; i++) B->bwt[i >> 3] |= (uint32_t)bw[i] << (28 - 4 * (i & 7)); /* first char in bits 31-28 */
+	bwtint_t occ[ALPHABET_SIZE] = { 0 };
+	for (bwtint_t i = 0; i < B->length; i++) {
+		if (i != B->sa0_index) { B->C[bw[i] + 1]++; occ[bw[i]]++; }
+		if (i % OCC_INTERVAL == 0) memcpy(&B->O[(i / OCC_INTERVAL) * ALPHABET_SIZE], occ, sizeof(occ));
+	}
+	for (int i = 1; i <= ALPHABET_SIZE; i++) B->C[i] += B->C[i - 1];
+	free(bw);
+	return B;
+}
+
+int index_bwt(const char *fastaFname, const char *extSAFname) { /* bwt.c:29-63 */
+	printf("**** BWT Index **** \n");
+	if (extSAFname) bwb_die("index: external eSAIS suffix arrays (-e) are not supported by this build");
+	size_t L = strlen(fastaFname) + 8;
+	char *annFname = (char *)malloc(L), *bwtFname = (char *)malloc(L), *refFname = (char *)malloc(L);
+	snprintf(annFname, L, "%s.ann", fastaFname);
+	snprintf(bwtFname, L, "%s.bwt", fastaFname);
+	snprintf(refFname, L, "%s.ref", fastaFname);
+	unsigned char *seq;
+	bwtint_t seqLen;
+	fasta2ref(fastaFname, refFname, annFname, &seq, &seqLen);
+	double t = wall();
+	bwt_t *B = construct_bwt(seq, seqLen);
+	printf("Total BWT construction time: %.2f sec\n", wall() - t);
+	free(seq);
+	store_bwt(B, bwtFname);
+	free(annFname); free(bwtFname); free(refFname);
+	free_bwt(B);
+	return 0;
+}

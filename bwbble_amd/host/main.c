@@ -1,0 +1,92 @@
+/* main.c - `bwbble` command line, same commands and flags as the reference (mg-aligner/main.c:38-160),
+ * plus -g <n_gpus> on align / aln2sam. */
+#include <getopt.h>
+#include <stdlib.h>
+#include <string.h>
+#include "bwb_host.h"
+
+static int usage(void) {
+	printf("Usage:   bwbble command [options] \n");
+	printf("Command: index    index sequences in the FASTA format\n");
+	printf("         align    exact or inexact read alignment (MI355X)\n");
+	printf("         fasta2ref    constructs a single linear reference from the input file \n");
+	printf("         aln2sam  convert alignment results to SAM file format for single-end mapping\n\n");
+	return 1;
+}
+static int align_usage(void) {
+	printf("Usage: bwbble align [options] <seq_fasta> <reads_fastq> <output_aln> \n");
+	printf("Options: M    mismatch penalty (default: 3)\n         O    gap open penalty (default: 11) \n         E    gap extend penalty (default: 4) \n");
+	printf("         n    maximum number of differences in the alignment (gaps and mismatches) (default: 0)\n");
+	printf("         l    length of the seed (seed := first seed_length chars of the read) (default: 32)\n");
+	printf("         k    maximum number of differences in the seed (default: 2)\n         o    maximum number of gap opens (default: 1)\n");
+	printf("         e    maximum number of gap extends (default: 6) \n         t    accepted for compatibility, ignored (the GPU path has no host threads knob)\n");
+	printf("         g    number of GPUs to use (default: 1)\n");
+	printf("         S    align with a single-genome reference (not supported by the GPU path yet)\n         P    use pre-calculated partial alignment results (not supported by the GPU path yet)\n\n");
+	return 1;
+}
+
+int main(int argc, char *argv[]) {
+	if (argc < 2) return usage();
+	if (strcmp(argv[1], "index") == 0) {
+		if (argc < 3) { printf("Usage: bwbble index [options] <seq_fasta> \n"); exit(1); }
+		char *esa = NULL;
+		int c;
+		while ((c = getopt(argc - 1, argv + 1, "e:")) >= 0) {
+			if (c == 'e') esa = optarg; else return 1;
+		}
+		index_bwt(argv[optind + 1], esa);
+	} else if (strcmp(argv[1], "align") == 0) {
+		if (argc < 5) { align_usage(); exit(1); }
+		aln_params_t params;
+		set_default_aln_params(&params);
+		int c, n_gpus = 1;
+		while ((c = getopt(argc - 1, argv + 1, "M:O:E:n:k:o:e:l:m:t:g:SP")) >= 0) {
+			switch (c) {
+			case 'M': params.mm_score = atoi(optarg); break;
+			case 'O': params.gapo_score = atoi(optarg); break;
+			case 'E': params.gape_score = atoi(optarg); break;
+			case 'n': params.max_diff = atoi(optarg); break;
+			case 'k': params.max_diff_seed = atoi(optarg); break;
+			case 'o': params.max_gapo = atoi(optarg); break;
+			case 'e': params.max_gape = atoi(optarg); break;
+			case 'l': params.seed_length = atoi(optarg); break;
+			case 'm': params.max_entries = atoi(optarg); break;
+			case 't': params.n_threads = atoi(optarg); break;
+			case 'g': n_gpus = atoi(optarg); break;
+			case 'S': params.is_multiref = 0; break;
+			case 'P': params.use_precalc = 1; break;
+			case '?': align_usage(); return 1;
+			default: return 1;
+			}
+		}
+		if (argc - 1 - optind < 3) { align_usage(); exit(1); }
+		align_reads(argv[optind + 1], argv[optind + 2], argv[optind + 3], &params, n_gpus);
+	} else if (strcmp(argv[1], "fasta2ref") == 0) {
+		if (argc < 3) { printf("Usage: bwbble fasta2ref <seq_fasta> \n"); exit(1); }
+		size_t L = strlen(argv[2]) + 8;
+		char *refFname = (char *)malloc(L), *annFname = (char *)malloc(L);
+		snprintf(refFname, L, "%s.ref", argv[2]);
+		snprintf(annFname, L, "%s.ann", argv[2]);
+		unsigned char *seq;
+		bwtint_t seqLen;
+		fasta2ref(argv[2], refFname, annFname, &seq, &seqLen);
+		free(seq); free(refFname); free(annFname);
+	} else if (strcmp(argv[1], "aln2sam") == 0) {
+		if (argc < 6) { printf("Usage: bwbble aln2sam [-S, -n, -g] <seq_fasta> <reads_fastq> <alns_aln> <out_sam> \n"); exit(1); }
+		int is_multiref = 1, max_diff = 6, n_gpus = 1, c;
+		while ((c = getopt(argc - 1, argv + 1, "n:g:S")) >= 0) {
+			switch (c) {
+			case 'S': is_multiref = 0; break;
+			case 'n': max_diff = atoi(optarg); break;
+			case 'g': n_gpus = atoi(optarg); break;
+			case '?': printf("Unknown option \n"); break;
+			default: return 1;
+			}
+		}
+		alns2sam(argv[optind + 1], argv[optind + 2], argv[optind + 3], argv[optind + 4], is_multiref, max_diff, n_gpus);
+	} else {
+		printf("Error: Unknown command '%s'\n", argv[1]);
+		usage();
+	}
+	return 0;
+}

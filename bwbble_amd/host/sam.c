@@ -1,0 +1,126 @@
+/*
+ * sam.c - `bwbble aln2sam`: .aln + FASTQ -> SAM, same text as the reference (mg-aligner/align.c:494-556 alns2sam,
+ * :562-652 print_aln2sam, :738-812 mapq / eval_aln).
+ *
+ * The only index work here is SA(aln.L) for the reported hit of every mapped read (align.c:786), an invPsi
+ * walk of up to 31 dependent rank queries (bwt.c:311-329).  It runs on the GPU for all reads at once
+ * (bwb_hip_locate); MAPQ (the only floating point in the tool), CIGAR and text stay on the host.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "bwb_host.h"
+
+#define SAM_FSU 4
+#define SAM_FSR 16
+
+static int mapq(int top1, int top2, int num_mm, int max_mm) { /* align.c:738-746 */
+	if (top1 == 0) return 23;
+	if (top1 > 1) return 0;
+	if (num_mm == max_mm) return 25;
+	if (top2 == 0) return 37;
+	int n = top2 >= 255 ? 255 : top2;
+	int q = (int)(4.343 * log(n) + 0.5);
+	return 23 < q ? 0 : 23 - q;
+}
+
+void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFname, int is_multiref, int max_diff, int n_gpus) {
+	(void)is_multiref; (void)n_gpus;
+	printf("**** BWBBLE Alignment Evaluation/SAM File Generation ****\n");
+	size_t Ln = strlen(fastaFname) + 8;
+	char *bwtFname = (char *)malloc(Ln), *annFname = (char *)malloc(Ln);
+	snprintf(bwtFname, Ln, "%s.bwt", fastaFname);
+	snprintf(annFname, Ln, "%s.ann", fastaFname);
+	bwt_t *BWT = load_bwt(bwtFname, 1);
+	fasta_annotations_t *ann = annf2ann(annFname);
+	alns_batch_t *alns = alnsf2alns_bin(alnsFname);
+	reads_t *reads = fastq2reads(readsFname);
+	FILE *sam = fopen(samFname, "w");
+	if (!sam) { perror(samFname); bwb_die("alns2sam: Cannot open SAM file: %s!", samFname); }
+	for (int i = 0; i < ann->num_seq; i++)                                           /* align.c:522-525 */
+		fprintf(sam, "@SQ\tSN:%s\tLN:%d\n", ann->seq_anns[i].name, (int)(ann->seq_anns[i].end_index - ann->seq_anns[i].start_index + 1));
+	fprintf(sam, "@PG\tID:bwbble\tPN:bwbble\tVN:0.1-r01\n");
+
+	const size_t n = reads->count < alns->n_reads ? reads->count : alns->n_reads;    /* align.c:535-537 */
+	/* SA(aln.L) of the first entry of every mapped read, on the GPU */
+	uint64_t *rows = (uint64_t *)malloc((n ? n : 1) * 8), *pos = (uint64_t *)malloc((n ? n : 1) * 8);
+	size_t *which = (size_t *)malloc((n ? n : 1) * sizeof(size_t));
+	size_t nm = 0;
+	for (size_t r = 0; r < n; r++)
+		if (alns->aln_off[r + 1] > alns->aln_off[r]) { rows[nm] = alns->alns[alns->aln_off[r]].L; which[nm] = r; nm++; }
+	if (nm) {
+		if (bwb_hip_device_count() < 1) bwb_die("alns2sam: no HIP device found (SA lookups run on the GPU)");
+		bwb_hip_ctx *ctx = NULL;
+		const bwtint_t hdr[5] = { BWT->length, BWT->num_words, BWT->num_sa, BWT->num_occ, BWT->sa0_index };
+		if (bwb_hip_ctx_create(0, hdr, BWT->C, BWT->bwt, BWT->O, &ctx) || bwb_hip_set_sa(ctx, BWT->SA, BWT->num_sa) ||
+		    bwb_hip_locate(ctx, rows, nm, pos))
+			bwb_die("alns2sam: %s", bwb_hip_last_error());
+		bwb_hip_ctx_destroy(ctx);
+	}
+	uint64_t *ref_pos = (uint64_t *)calloc(n ? n : 1, 8);
+	for (size_t k = 0; k < nm; k++) ref_pos[which[k]] = pos[k];
+
+	unsigned char path[272];
+	char *line = (char *)malloc(70000);
+	for (size_t r = 0; r < n; r++) {
+		const bwb_aln *e = alns->alns + alns->aln_off[r];
+		const uint64_t ne = alns->aln_off[r + 1] - alns->aln_off[r];
+		const int len = reads->len[r];
+		const uint8_t *seq = reads->seq + (size_t)r * reads->stride;
+		const char *name = reads->raw + reads->name_off[r];
+		const char *qual = reads->raw + reads->qual_off[r];
+		if (ne == 0) { /* unmapped, align.c:629-651 (aln_strand is 0 for a read that was never evaluated) */
+			fprintf(sam, "%.*s\t%d\t*\t0\t0\t*\t*\t0\t0\t", (int)reads->name_len[r], name, SAM_FSU);
+			for (int i = 0; i < len; i++) line[i] = "AGCTN"[seq[i]];
+			fwrite(line, 1, (size_t)len, sam);
+			fputc('\t', sam);
+			fwrite(qual, 1, (size_t)len, sam);
+			fputc('\n', sam);
+			continue;
+		}
+		/* eval_aln, align.c:760-812 */
+		int top1 = 0, top2 = 0;
+		const int best_score = e[0].score;
+		for (uint64_t i = 0; i < ne; i++) {
+			if (e[i].score > best_score) top2 += (int)(e[i].U - e[i].L + 1);
+			else top1 += (int)(e[i].U - e[i].L + 1);
+		}
+		int alen = aln_path_bytes(&e[0], path);
+		int ref_len = alen;                                                          /* get_aln_length :748-757 */
+		for (int i = 0; i < alen; i++) if (path[i] == 1) ref_len--;
+		const uint64_t rp = ref_pos[r];
+		int strand;
+		uint64_t aln_pos;
+		if (rp > (BWT->length - 1) / 2) { strand = 0; aln_pos = ((BWT->length - 1) - rp - 1) - (uint64_t)ref_len + 1; }
+		else { strand = 1; aln_pos = rp; }
+		const int mq = mapq(top1, top2, e[0].num_mm, max_diff);
+		int seqid = -1;
+		for (int i = 0; i < ann->num_seq; i++)
+			if (aln_pos >= ann->seq_anns[i].start_index && aln_pos <= ann->seq_anns[i].end_index) { seqid = i; break; }
+		if (seqid < 0) bwb_die("alns2sam: read %zu maps outside every annotated sequence", r); /* the reference indexes seq_anns[-1] here */
+		fprintf(sam, "%.*s\t%d\t%s\t", (int)reads->name_len[r], name, strand ? SAM_FSR : 0, ann->seq_anns[seqid].name);
+		fprintf(sam, "%d\t%d\t", (int)(aln_pos - ann->seq_anns[seqid].start_index + 1), mq);
+		if (strand) for (int i = 0; i < alen >> 1; i++) { unsigned char t = path[alen - 1 - i]; path[alen - 1 - i] = path[i]; path[i] = t; }
+		/* CIGAR: runs of the path walked from its end to its start (align.c:588-609) */
+		int i = alen - 1;
+		while (i >= 0) {
+			int j = i;
+			while (j >= 0 && path[j] == path[i]) j--;
+			fprintf(sam, "%d%c", i - j, "MID"[path[i]]);
+			i = j;
+		}
+		fprintf(sam, "\t*\t0\t0\t");
+		if (strand) for (int k = 0; k < len; k++) { const int c = seq[len - 1 - k]; line[k] = "AGCTN"[c > 3 ? 4 : 3 - c]; } /* read->rc */
+		else for (int k = 0; k < len; k++) line[k] = "AGCTN"[seq[k]];
+		fwrite(line, 1, (size_t)len, sam);
+		fputc('\t', sam);
+		if (strand) { for (int k = 0; k < len; k++) line[k] = qual[len - 1 - k]; fwrite(line, 1, (size_t)len, sam); }
+		else fwrite(qual, 1, (size_t)len, sam);
+		fputc('\n', sam);
+	}
+	printf("Processed %zu reads.\n", n);
+	free(line); free(rows); free(pos); free(which); free(ref_pos);
+	free(bwtFname); free(annFname);
+	free_bwt(BWT); free_reads(reads); free_alns_batch(alns); free_ann(ann);
+	fclose(sam);
+}

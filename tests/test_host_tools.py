@@ -1,0 +1,102 @@
+"""Host-side C tools (bwbble_amd/host): index builder, .aln reader/writer, FASTQ reader.
+CPU tests check file-format parity with the reference's golden files; GPU tests run the CLI end to end."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import bwbble_amd as bw
+from golden.make_golden import ALIGN_CONFIGS
+
+
+def run(cmd):
+    return subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+
+
+@pytest.fixture(scope="module")
+def toy_dir(built, golden, tmp_path_factory):
+    d = tmp_path_factory.mktemp("toy")
+    shutil.copy(os.path.join(golden, "toy.fa"), d / "toy.fa")
+    run([bw.HOST_BIN, "index", str(d / "toy.fa")])
+    return d
+
+
+def test_index_files_identical_to_reference(toy_dir, golden):
+    """`bwbble index` (own suffix sort) writes the reference's .bwt and .ann byte for byte (bwt.c:66-82, io.c:292-296)."""
+    for ext in (".bwt", ".ann"):
+        assert open(toy_dir / ("toy.fa" + ext), "rb").read() == open(os.path.join(golden, "toy.fa" + ext), "rb").read()
+    ref = np.fromfile(toy_dir / "toy.fa.ref", dtype=np.uint8)
+    n = len(ref) // 2
+    compl = np.array([0, 15, 8, 7, 4, 11, 12, 3, 2, 13, 10, 5, 6, 9, 14, 1], dtype=np.uint8)  # iupacCompl io.h:32
+    assert np.array_equal(ref[n:], compl[ref[:n]][::-1])
+
+
+def test_index_edge_cases(built, tmp_path):
+    """Lower-case input, non-IUPAC characters (-> N), repeats/duplicated records, an odd number of characters:
+    checked against a naive suffix sort."""
+    fa = tmp_path / "e.fa"
+    fa.write_text(">a\nacgtACGTnnRYKM\nACGTACGTACGTA\n>b dup\nACGTACGTACGTA\n>c\nAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAX\n")
+    run([bw.HOST_BIN, "index", str(fa)])
+    b = bw.BwtFile(str(fa) + ".bwt", load_sa=True)
+    text = np.fromfile(str(fa) + ".ref", dtype=np.uint8)
+    n = len(text)
+    assert b.length == n + 1
+    sa = sorted(range(n + 1), key=lambda i: bytes(text[i:]))  # end of text smallest, like is_sa (is.c:197-206)
+    bwt = [0 if s == 0 else int(text[s - 1]) for s in sa]
+    got = [(int(b.bwt[i >> 3]) >> (28 - 4 * (i & 7))) & 15 for i in range(n + 1)]
+    assert got == bwt
+    assert b.sa0_index == sa.index(0)
+    assert [int(v) for v in b.SA] == [sa[i] for i in range(0, n + 1, 32)]
+    cnt = np.bincount(text, minlength=16)
+    assert [int(v) for v in b.C] == [0] + list(np.cumsum(cnt))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap"])
+def test_cli_align_writes_reference_aln(toy_dir, golden, name):
+    out = toy_dir / f"{name}.aln"
+    log = run([bw.HOST_BIN, "align"] + ALIGN_CONFIGS[name] + [str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(out)])
+    assert "Processed 600 reads" in log
+    assert open(out, "rb").read() == open(os.path.join(golden, f"toy_{name}.aln"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_align_multi_chunk_order(toy_dir, golden):
+    """Chunks pulled by the per-GPU host threads are written back in input order."""
+    out = toy_dir / "chunks.aln"
+    env = dict(os.environ, BWB_CHUNK="97")
+    subprocess.run([bw.HOST_BIN, "align", "-n", "3", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(out)],
+                   check=True, env=env, stdout=subprocess.DEVNULL)
+    assert open(out, "rb").read() == open(os.path.join(golden, "toy_n3.aln"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fq,aln,sam", [("toy.fq", "toy_n3.aln", "toy_n3.sam"), ("ragged.fq", "ragged_n4gap.aln", "ragged_n4gap.sam")])
+def test_cli_aln2sam_writes_reference_sam(toy_dir, golden, fq, aln, sam):
+    out = toy_dir / (sam + ".out")
+    run([bw.HOST_BIN, "aln2sam", str(toy_dir / "toy.fa"), os.path.join(golden, fq), os.path.join(golden, aln), str(out)])
+    assert open(out).read() == open(os.path.join(golden, sam)).read()
+
+
+@pytest.mark.gpu
+def test_locate_matches_oracle(toy_dir, oracle, golden):
+    b = bw.BwtFile(os.path.join(golden, "toy.fa.bwt"), load_sa=True)
+    ctx = bw.Context(b)
+    ctx.set_sa(b.SA)
+    rng = np.random.default_rng(3)
+    rows = np.concatenate([rng.integers(0, b.length, 4000), [0, b.length - 1, b.sa0_index, 32, 31]]).astype(np.uint64)
+    got = ctx.locate(rows)
+    idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"), load_sa=True)
+    want = np.array([oracle.lib.bwb_or_SA(idx, int(r)) for r in rows], dtype=np.uint64)
+    assert np.array_equal(got, want)
+    ctx.close()
+
+
+def test_cli_align_without_gpu_fails_loudly(toy_dir, golden):
+    if bw.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([bw.HOST_BIN, "align", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(toy_dir / "x.aln")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stdout
