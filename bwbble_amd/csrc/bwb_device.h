@@ -9,8 +9,7 @@
  * separate O row (128 B, bwt.c:288) + packed BWT words (64 B, io.c:590-609):
  *   slice s=0..3 : uint32 {cnt[2s], cnt[2s+1], cnt[2s+8], cnt[2s+9]}
  *                  cnt[c] = #c in BWT[superblock_start .. 128b-1]  (EXCLUSIVE of this block, sentinel
- *                  row excluded as in compute_O bwt.c:284); the cnt[0] slot instead holds the code of
- *                  the block's first character (needed for the O_alphabet quirk, bwt.c:780).
+ *                  row excluded as in compute_O bwt.c:284).
  *   slice 4+w    : uint32 {p0,p1,p2,p3} bit-planes of characters [32w, 32w+32): bit j of p_k is bit k
  *                  of the 4-bit code at block offset 32w+j.
  * Absolute counts need > 32 bits on GRCh37-scale texts, so a superblock (2^24 blocks = 2^31 chars)
@@ -93,9 +92,9 @@ __device__ __forceinline__ void rank_finish(const RankReq &r, const uint64_t *s_
 	const uint32_t pop0 = (pd >> sh) & 0xFF, pop1 = (pd >> (sh + 8)) & 0xFF;
 	/* counts: lanes 0..3 own (x,y); lanes 4..7 take (z,w) of lane ol-4 */
 	const uint32_t cz = __shfl_up(q.z, 4, 8), cw = __shfl_up(q.w, 4, 8);
-	const uint32_t first = __shfl(q.x, lane & ~7) & 15u;
+	/* first character of the block (for the bwt.c:780 quirk): bit 0 of the four planes held by lane 4 */
+	const uint32_t first = __shfl((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);
 	uint32_t c0 = ol < 4 ? q.x : cz, c1 = ol < 4 ? q.y : cw;
-	if (ol == 0) c0 = 0; /* slot of code 0 holds the first-char nibble */
 	if (!r.regular) { c0 = 0; c1 = 0; }
 	const uint64_t *brow = s_base + r.row * 16 + 2 * ol;
 	v0 = brow[0] + c0 + pop0;

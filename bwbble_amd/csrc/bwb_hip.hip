@@ -107,7 +107,7 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	for (uint64_t sb = 0; sb < nsb; sb++) {
 		const uint64_t blk = sb << BWB_SB_SHIFT;
 		const uint32_t first = bwt[blk * 16] >> 28;
-		for (int j = 1; j < 16; j++) sbcount[sb * 16 + j] = O[blk * 16 + j] - (first == (uint32_t)j ? 1 : 0);
+		for (int j = 0; j < 16; j++) sbcount[sb * 16 + j] = O[blk * 16 + j] - ((first == (uint32_t)j && !(j == 0 && blk * 128 == hdr[4])) ? 1 : 0);
 	}
 	for (uint64_t sb = 0; sb < BWB_NSB_MAX; sb++)
 		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
@@ -130,7 +130,7 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 		HIPCHK(hipMemcpy(d_bwt, bwt + w0, nw * 4, hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(d_O, O + b0 * 16, nb * 128, hipMemcpyHostToDevice));
 		const uint64_t nthreads = nb * 8;
-		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt, d_O, b0, nb, nw, d_sbc, c->d_buckets);
+		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt, d_O, b0, nb, nw, hdr[4], d_sbc, c->d_buckets);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipStreamSynchronize(c->stream));
 	}

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
  * Index re-layout: reference arrays (bwt words io.c:590-609, O rows bwt.c:280-291) -> buckets
  * One thread per 16-byte slice. blk0 = first block of this chunk; bwt/O point at the chunk.
  * ========================================================================================== */
-__global__ void k_relayout(const uint32_t *bwt, const uint64_t *O, uint64_t blk0, uint64_t nblk_chunk, uint64_t nwords_chunk,
+__global__ void k_relayout(const uint32_t *bwt, const uint64_t *O, uint64_t blk0, uint64_t nblk_chunk, uint64_t nwords_chunk, uint64_t sa0_index,
                            const uint64_t *sbcount /* [NSB][16] exclusive counts at superblock starts */, uint4 *buckets) {
 	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nblk_chunk * 8) return;
@@ -654,9 +654,10 @@ __global__ void k_relayout(const uint32_t *bwt, const uint64_t *O, uint64_t blk0
 		uint32_t v[4];
 		for (int q = 0; q < 4; q++) {
 			const int c = cs[q];
-			v[q] = (uint32_t)(row[c] - (first == (uint32_t)c ? 1u : 0u) - sb[c]);
+			/* O rows are inclusive of position 128k and skip the sentinel row (bwt.c:284-288) */
+			const bool counted = first == (uint32_t)c && !(c == 0 && blk * 128 == sa0_index);
+			v[q] = (uint32_t)(row[c] - (counted ? 1u : 0u) - sb[c]);
 		}
-		if (sl == 0) v[0] = first; /* code 0 is never ranked: its slot carries the block's first char */
 		o = make_uint4(v[0], v[1], v[2], v[3]);
 	} else {
 		const int w = sl - 4;
@@ -749,9 +750,11 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_
 			const uint32_t code = __shfl(code_here, srcl);
 			uint64_t v0, v1;
 			rank_finish(ra, s_base, ol, lane, false, v0, v1);
-			/* C[c] + O(c,i): held by lane c>>1 */
+			/* C[c] + O(c,i): held by lane c>>1.  The sentinel row is stored as code 0 but is not a '$' (bwt.c:364) */
 			const uint64_t mine = (code & 1u) ? v1 : v0;
-			i = oct_bcast64(mine, (lane & ~7) + (int)(code >> 1));
+			uint64_t nxt = oct_bcast64(mine, (lane & ~7) + (int)(code >> 1));
+			if (code == 0 && ra.regular && sa0_index >= (i & ~127ull) && sa0_index <= i) nxt--;
+			i = nxt;
 			j++;
 		}
 		if (ol == 0) out[q] = (SA[i >> 5] + j) % ix.length;
