@@ -13,7 +13,10 @@
  *   slice 4+w    : uint32 {p0,p1,p2,p3} bit-planes of characters [32w, 32w+32): bit j of p_k is bit k
  *                  of the 4-bit code at block offset 32w+j.
  * Absolute counts need > 32 bits on GRCh37-scale texts, so a superblock (2^24 blocks = 2^31 chars)
- * base table base[sb][c] = C[c] + #c before the superblock lives in LDS (<= 10 rows x 128 B).
+ * base table base[sb][c] = C[c] + #c before the superblock lives in LDS (<= 10 rows).
+ *
+ * Positions are a template parameter P: uint32_t when the BWT has < 2^32 - 1 rows (everything up
+ * to ~2 G forward characters), uint64_t otherwise (GRCh37 + 1000G).  "-1" is ~P(0).
  */
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,54 +35,71 @@ struct DevIndex {
 	uint64_t base[BWB_BASE_ROWS][16];
 };
 
+/* ---- intra-octet data movement on the DPP path (no LDS traffic) ------------------------------ */
+#define DPP_QUAD_XOR1 0xB1      /* quad_perm:[1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E      /* quad_perm:[2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141   /* row_half_mirror: lane i <- lane 7-i of its 8-lane half row */
+#define DPP_ROW_SHR4 0x114      /* row_shr:4 */
+
+template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+/* all-reduce over the 8 lanes of an octet.  After the two quad steps every lane of a quad holds the
+ * quad's value, so the mirrored half row delivers "the other quad" to each lane. */
 __device__ __forceinline__ uint32_t oct_or(uint32_t v) {
-	v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4);
+	v |= dpp<DPP_QUAD_XOR1>(v); v |= dpp<DPP_QUAD_XOR2>(v); v |= dpp<DPP_HALF_MIRROR>(v);
 	return v;
 }
 __device__ __forceinline__ uint32_t oct_add(uint32_t v) {
-	v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+	v += dpp<DPP_QUAD_XOR1>(v); v += dpp<DPP_QUAD_XOR2>(v); v += dpp<DPP_HALF_MIRROR>(v);
 	return v;
 }
-__device__ __forceinline__ uint64_t oct_bcast64(uint64_t v, int lane_in_wave) {
+/* lanes 4..7 of every octet receive the value of lane-4 (lanes 0..3 receive garbage/0) */
+__device__ __forceinline__ uint32_t oct_shr4(uint32_t v) { return dpp<DPP_ROW_SHR4>(v); }
+
+__device__ __forceinline__ uint32_t oct_bcast(uint32_t v, int lane_in_wave) { return (uint32_t)__shfl((int)v, lane_in_wave); }
+__device__ __forceinline__ uint64_t oct_bcast(uint64_t v, int lane_in_wave) {
 	uint32_t lo = __shfl((uint32_t)v, lane_in_wave), hi = __shfl((uint32_t)(v >> 32), lane_in_wave);
 	return ((uint64_t)hi << 32) | lo;
 }
 
 /* One side of a visit pair, before the data arrives */
-struct RankReq {
-	uint64_t pos;
+template <typename P> struct RankReq {
+	P pos;
 	bool regular;                       /* false for pos == -1 / length-1: no memory touched */
 	int row;                            /* base-table row */
 	uint4 q;                            /* this lane's 16-byte slice */
 };
 
-__device__ __forceinline__ void rank_issue(const DevIndex &ix, uint64_t pos, int ol, RankReq &r) {
+template <typename P>
+__device__ __forceinline__ void rank_issue(const uint4 *__restrict__ buckets, P last_row, P pos, int ol, RankReq<P> &r) {
 	r.pos = pos;
-	const bool neg = (pos == ~0ull), end = (pos == ix.length - 1);
+	const bool neg = (pos == (P)~(P)0), end = (pos == last_row);
 	r.regular = !(neg || end);
-	const uint64_t blk = pos >> 7;
-	r.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)(blk >> BWB_SB_SHIFT));
+	const P blk = pos >> 7;
+	r.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BWB_SB_SHIFT));
 	r.q = make_uint4(0, 0, 0, 0);
-	if (r.regular) r.q = ix.buckets[blk * 8 + ol];
+	if (r.regular) r.q = buckets[(size_t)blk * 8 + ol];
 }
 
 /*
  * Finishes a visit: v0/v1 = C[j] + Occ(j, pos) for this lane's codes j = 2*ol and 2*ol+1.
- * quirk != 0 reproduces O_alphabet (bwt.c:423-437): codes 5, 9, 11, 13 get
+ * QUIRK reproduces O_alphabet (bwt.c:423-437): codes 5, 9, 11, 13 get
  * C[j] - [first char of the block == j] instead of their count.  s_base is the LDS copy of
- * DevIndex::base.
+ * DevIndex::base (as P).
  */
-__device__ __forceinline__ void rank_finish(const RankReq &r, const uint64_t *s_base, int ol, int lane, bool quirk,
-                                            uint64_t &v0, uint64_t &v1) {
+template <typename P, bool QUIRK>
+__device__ __forceinline__ void rank_finish(const RankReq<P> &r, const P *s_base, int ol, int lane, P &v0, P &v1) {
 	const uint4 q = r.q;
 	/* position mask of this lane's 32-character sub-block (lanes 0..3 hold counts: empty mask) */
 	const int off = (int)(r.pos & 127);
 	const int nvalid = off + 1 - 32 * (ol - 4);
-	uint32_t m = (ol < 4 || nvalid <= 0 || !r.regular) ? 0u : (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
+	const uint32_t m = (ol < 4 || nvalid <= 0 || !r.regular) ? 0u : (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
 	const uint32_t p0 = q.x, p1 = q.y, p2 = q.z, p3 = q.w;
-	const uint32_t n0 = ~p0, n1 = ~p1, n2 = ~p2, n3 = ~p3;
-	const uint32_t a0 = n0 & n1, a1 = p0 & n1, a2 = n0 & p1, a3 = p0 & p1;           /* code & 3  */
-	const uint32_t b0 = n2 & n3 & m, b1 = p2 & n3 & m, b2 = n2 & p3 & m, b3 = p2 & p3 & m; /* code >> 2 */
+	const uint32_t n0 = ~p0, n1 = ~p1;
+	const uint32_t a0 = n0 & n1, a1 = p0 & n1, a2 = n0 & p1, a3 = p0 & p1;                 /* code & 3  */
+	const uint32_t m2 = m & ~p2, m2p = m & p2;
+	const uint32_t b0 = m2 & ~p3, b1 = m2p & ~p3, b2 = m2 & p3, b3 = m2p & p3;             /* code >> 2 */
 	uint32_t pc0 = __popc(a0 & b0) | (__popc(a1 & b0) << 8) | (__popc(a2 & b0) << 16) | (__popc(a3 & b0) << 24);
 	uint32_t pc1 = __popc(a0 & b1) | (__popc(a1 & b1) << 8) | (__popc(a2 & b1) << 16) | (__popc(a3 & b1) << 24);
 	uint32_t pc2 = __popc(a0 & b2) | (__popc(a1 & b2) << 8) | (__popc(a2 & b2) << 16) | (__popc(a3 & b2) << 24);
@@ -91,17 +111,17 @@ __device__ __forceinline__ void rank_finish(const RankReq &r, const uint64_t *s_
 	const int sh = (ol & 1) * 16;
 	const uint32_t pop0 = (pd >> sh) & 0xFF, pop1 = (pd >> (sh + 8)) & 0xFF;
 	/* counts: lanes 0..3 own (x,y); lanes 4..7 take (z,w) of lane ol-4 */
-	const uint32_t cz = __shfl_up(q.z, 4, 8), cw = __shfl_up(q.w, 4, 8);
-	/* first character of the block (for the bwt.c:780 quirk): bit 0 of the four planes held by lane 4 */
-	const uint32_t first = __shfl((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);
+	const uint32_t cz = oct_shr4(q.z), cw = oct_shr4(q.w);
 	uint32_t c0 = ol < 4 ? q.x : cz, c1 = ol < 4 ? q.y : cw;
 	if (!r.regular) { c0 = 0; c1 = 0; }
-	const uint64_t *brow = s_base + r.row * 16 + 2 * ol;
+	const P *brow = s_base + r.row * 16 + 2 * ol;
 	v0 = brow[0] + c0 + pop0;
 	v1 = brow[1] + c1 + pop1;
-	if (quirk && r.regular) {
-		/* only odd codes 5, 9, 11, 13 (lanes 2, 4, 5, 6) */
-		const int j1 = 2 * ol + 1;
-		if (j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13) v1 = s_base[BWB_ROW_NEG * 16 + j1] - (first == (uint32_t)j1 ? 1u : 0u);
+	if (QUIRK) {
+		/* first character of the block (bwt.c:780): bit 0 of the four planes held by lane 4 */
+		const uint32_t first = oct_bcast((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);
+		const int j1 = 2 * ol + 1; /* only odd codes 5, 9, 11, 13 (lanes 2, 4, 5, 6) */
+		if (r.regular && (j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13))
+			v1 = s_base[BWB_ROW_NEG * 16 + j1] - (first == (uint32_t)j1 ? (P)1 : (P)0);
 	}
 }

@@ -19,6 +19,7 @@
 #include <vector>
 #include "../../include/bwbble_hip.h"
 #include "bwb_kernels.h"
+#include "bwb_lane.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
@@ -28,10 +29,11 @@ static int fail(int code, const std::string &m) { g_err = m; return code; }
 		if (e_ != hipSuccess) return fail(BWB_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));  \
 	} while (0)
 
+/* per-lane scratch of one class (class 0 = every resident lane, classes 1/2 = fewer lanes with larger lists) */
 struct ScratchClass {
 	void *mem = nullptr;
-	size_t bytes = 0, slot_bytes = 0;
-	Scratch sc{};
+	size_t bytes = 0;
+	LaneScratch sc{};
 	uint32_t blocks = 0;
 };
 
@@ -42,6 +44,7 @@ struct bwb_hip_ctx {
 	uint4 *d_buckets = nullptr;
 	uint64_t sa0_index = 0, num_sa = 0;
 	uint64_t *d_SA = nullptr;
+	bool pos32 = true;                  /* BWT rows fit 32-bit positions */
 	/* batch */
 	bool uploaded = false, ran = false;
 	bwb_params p{};
@@ -57,6 +60,11 @@ struct bwb_hip_ctx {
 	uint64_t log_cap = 0, sorted_cap = 0;
 	uint32_t dstride = 0, dseed_off = 0;
 	ScratchClass cls[3];
+	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes */
+	size_t pool_bytes = 0;
+	unsigned int *d_pool_bump = nullptr;
+	uint32_t *d_dbg_iters = nullptr;    /* BWB_DEBUG_ITERS: per-read iteration counts */
+	bool wide = false;                  /* 32-byte heap entries (64-bit positions or max_gapo > 1) */
 	std::vector<uint8_t> h_status;
 	std::vector<uint64_t> h_aln_off;
 	std::vector<bwb_aln> h_alns;
@@ -116,6 +124,7 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	c->ix.length = length;
 	c->ix.nblk = nblk;
 	c->sa0_index = hdr[4];
+	c->pos32 = length < 0xFFFFFFFFull && !getenv("BWB_FORCE_POS64");
 
 	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk */
 	const uint64_t CH = 1ull << 20;
@@ -151,6 +160,7 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 	hipSetDevice(c->device);
 	free_batch(c);
 	for (auto &k : c->cls) hipFree(k.mem);
+	hipFree(c->d_pool); hipFree(c->d_pool_bump);
 	hipFree(c->d_log); hipFree(c->d_sorted); hipFree(c->d_buckets); hipFree(c->d_counter); hipFree(c->d_count);
 	hipFree(c->d_stats); hipFree(c->d_SA);
 	if (c->ev0) hipEventDestroy(c->ev0);
@@ -161,54 +171,65 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 
 static uint32_t pad16(uint32_t v) { return (v + 15u) & ~15u; }
 
-/* per-octet LDS bytes of k_search and its sub-array paddings */
-static void search_lds(const bwb_hip_ctx *c, uint32_t &oct_bytes, uint32_t &lpad, uint32_t &spad, uint32_t &nbpad, size_t &total) {
-	lpad = pad16(c->maxlen ? c->maxlen : 1);
-	spad = pad16(c->kp.seed_length > 0 ? (uint32_t)c->kp.seed_length : 1);
-	nbpad = pad16((uint32_t)c->kp.num_buckets) ;
-	oct_bytes = 32 + 4 * nbpad + lpad + spad + lpad;
-	oct_bytes = pad16(oct_bytes);
-	total = (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)BWB_OCTS_PER_BLOCK * oct_bytes;
+static size_t lane_lds(const bwb_hip_ctx *c) {
+	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)2 * KID_ROWS * LANE_BLOCK * (c->pos32 ? 4 : 8);
 }
-static size_t calcd_lds(const bwb_hip_ctx *c) {
-	return (size_t)BWB_BASE_ROWS * 16 * 8 + BWB_OCTS_PER_BLOCK * 4 * 8 + (size_t)BWB_OCTS_PER_BLOCK * pad16(c->stride);
+
+static int ensure_pool(bwb_hip_ctx *c) {
+	if (c->d_pool) return BWB_OK;
+	size_t fr = 0, tot = 0;
+	hipMemGetInfo(&fr, &tot);
+	size_t want = (size_t)64 << 30;
+	if (getenv("BWB_POOL_GB")) want = (size_t)atol(getenv("BWB_POOL_GB")) << 30;
+	if (want > fr / 2) want = fr / 2;
+	want &= ~(size_t)4095;
+	if (want < ((size_t)64 << 20)) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
+	HIPCHK(hipMalloc(&c->d_pool, want));
+	HIPCHK(hipMalloc(&c->d_pool_bump, 64));
+	c->pool_bytes = want;
+	return BWB_OK;
 }
 
 static int ensure_class(bwb_hip_ctx *c, int k) {
+	int rc = ensure_pool(c);
+	if (rc) return rc;
 	ScratchClass &s = c->cls[k];
-	uint32_t nchunks, acap, lcap, blocks;
+	uint32_t blocks, lcap, acap;
 	if (k == 0) {
-		uint32_t o, l, sp, nb; size_t lds;
-		search_lds(c, o, l, sp, nb, lds);
-		int occ = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search, BWB_BLOCK, lds) != hipSuccess || occ < 1) occ = 2;
-		if (occ > 4) occ = 4;
-		blocks = (uint32_t)(c->num_cu * occ);
-		nchunks = 1024; acap = 256; lcap = 2048;
+		int bpc = 2;
+		if (getenv("BWB_BLOCKS_PER_CU")) bpc = atoi(getenv("BWB_BLOCKS_PER_CU"));
+		if (bpc < 1) bpc = 1;
+		blocks = (uint32_t)(c->num_cu * bpc); lcap = 1024; acap = 64;
 	} else if (k == 1) {
-		blocks = 32; nchunks = 32768; acap = 4096; lcap = 65536;
+		blocks = 64; lcap = 32768; acap = 2048;
 	} else {
-		blocks = 4;
-		nchunks = (uint32_t)((uint64_t)c->kp.max_entries / 16 + 2 * (uint64_t)c->kp.num_buckets + 16);
-		if (nchunks < 65536) nchunks = 65536;
-		acap = 1u << 16; lcap = 1u << 20;
+		blocks = 4; lcap = 1u << 20; acap = 1u << 16;
 	}
-	const size_t slot_bytes = (size_t)nchunks * 512 + (size_t)nchunks * 4 + (size_t)acap * 32 + (size_t)lcap * 32;
-	const size_t slots = (size_t)blocks * BWB_OCTS_PER_BLOCK;
-	const size_t bytes = slot_bytes * slots;
-	if (s.mem && s.bytes >= bytes && s.sc.nchunks == nchunks && s.blocks == blocks) return BWB_OK;
-	if (s.mem) { hipFree(s.mem); s.mem = nullptr; }
-	size_t fr = 0, tot = 0;
-	hipMemGetInfo(&fr, &tot);
-	if (bytes + (1ull << 30) > fr) return fail(BWB_E_HIP, "not enough device memory for the per-read scratch (class " + std::to_string(k) + ")");
-	HIPCHK(hipMalloc(&s.mem, bytes));
-	s.bytes = bytes; s.slot_bytes = slot_bytes; s.blocks = blocks;
+	const uint32_t nslots = blocks * LANE_BLOCK;
+	const uint32_t wstride = c->maxlen + 1;
+	const uint32_t nb = (uint32_t)c->kp.num_buckets;
+	const size_t isz = c->pos32 ? 8 : 16;
+	const size_t b_bstate = (size_t)nb * nslots * 4, b_lists = (size_t)nslots * 2 * lcap * isz, b_alns = (size_t)nslots * acap * 32,
+	             b_winfo = 0;
+	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+	const size_t bytes = al(b_bstate) + al(b_lists) + al(b_alns) + al(b_winfo);
+	if (!(s.mem && s.bytes >= bytes)) {
+		if (s.mem) { hipFree(s.mem); s.mem = nullptr; }
+		size_t fr = 0, tot = 0;
+		hipMemGetInfo(&fr, &tot);
+		if (bytes + ((size_t)1 << 30) > fr) return fail(BWB_E_HIP, "not enough device memory for the per-lane scratch (class " + std::to_string(k) + ")");
+		HIPCHK(hipMalloc(&s.mem, bytes));
+		s.bytes = bytes;
+	}
 	unsigned char *base = (unsigned char *)s.mem;
-	s.sc.ent = (uint4 *)base; base += slots * (size_t)nchunks * 512;
-	s.sc.cprev = (uint32_t *)base; base += slots * (size_t)nchunks * 4;
-	s.sc.alns = (uint4 *)base; base += slots * (size_t)acap * 32;
-	s.sc.lists = (ulonglong2 *)base;
-	s.sc.nchunks = nchunks; s.sc.acap = acap; s.sc.lcap = lcap;
+	s.sc.bstate = (uint32_t *)base; base += al(b_bstate);
+	s.sc.lists = (void *)base; base += al(b_lists);
+	s.sc.alns = (uint4 *)base; base += al(b_alns);
+	s.sc.winfo = (uint2 *)base;
+	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = wstride;
+	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump;
+	s.sc.pool_cap = (uint32_t)std::min<size_t>(c->pool_bytes / (c->wide ? 2048 : 1024), (size_t)1 << 26);
+	s.blocks = blocks;
 	return BWB_OK;
 }
 
@@ -232,8 +253,10 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
 	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb };
 	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
-	c->dseed_off = pad16(maxlen ? maxlen : 1);
-	c->dstride = c->dseed_off + pad16(p->seed_length ? p->seed_length : 1);
+	c->wide = !c->pos32 || p->max_gapo > 1;
+	/* per read: u16 {D[i-1], D[i-2]} for i = 0..maxlen+1, then u16 {Dseed[si-1], Dseed[si-2]}, then the N count */
+	c->dseed_off = pad16(2 * (maxlen + 2));
+	c->dstride = 2 * c->dseed_off + 16;
 	const size_t nr = n_reads ? n_reads : 1;
 	if (nr > c->cap_reads || nr * stride > c->cap_readbytes || nr * c->dstride > c->cap_dbuf) {
 		free_batch(c);
@@ -259,6 +282,7 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 		HIPCHK(hipMalloc(&c->d_log, want * 32));
 		c->log_cap = want;
 	}
+	if (getenv("BWB_DEBUG_ITERS")) { hipFree(c->d_dbg_iters); c->d_dbg_iters = nullptr; HIPCHK(hipMalloc(&c->d_dbg_iters, nr * 4)); HIPCHK(hipMemset(c->d_dbg_iters, 0, nr * 4)); }
 	int rc = ensure_class(c, 0);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -271,6 +295,7 @@ static Batch make_batch(bwb_hip_ctx *c, const uint32_t *worklist, uint32_t n_wor
 	b.reads = c->d_reads; b.lens = c->d_lens; b.n_reads = c->n_reads; b.stride = c->stride;
 	b.dbuf = c->d_dbuf; b.dstride = c->dstride; b.dseed_off = c->dseed_off;
 	b.worklist = worklist; b.n_work = n_work; b.counter = c->d_counter; b.status = c->d_status;
+	b.dbg_iters = c->d_dbg_iters;
 	return b;
 }
 
@@ -286,22 +311,24 @@ static int collect(bwb_hip_ctx *c, uint8_t want, std::vector<uint32_t> &ids) {
 
 static int launch_calc_d(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work, int32_t *dbgD, int32_t *dbgDs) {
 	ScratchClass &s = c->cls[k];
-	Scratch sc = s.sc;
-	/* calculate_d only needs the two interval lists: give it the whole slot */
-	sc.lists = (ulonglong2 *)s.mem;
-	sc.lcap = (uint32_t)std::min<size_t>(s.slot_bytes / 32, 1u << 24);
 	Batch b = make_batch(c, wl, n_work);
 	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
-	const uint32_t grid = std::min<uint32_t>(s.blocks, (n_work + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK);
+	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
+	const size_t lds = lane_lds(c);
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
-	hipLaunchKernelGGL(k_calc_d, dim3(grid ? grid : 1), dim3(BWB_BLOCK), calcd_lds(c), c->stream, c->ix, b, c->kp, sc, dbgD, dbgDs,
-	                   c->maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats);
+	if (c->pos32)
+		hipLaunchKernelGGL(kl_calc_d<uint32_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, dbgD, dbgDs,
+		                   c->maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats);
+	else
+		hipLaunchKernelGGL(kl_calc_d<uint64_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, dbgD, dbgDs,
+		                   c->maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	float ms = 0;
 	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->stats.ms_calc_d += ms; c->stats.launches_calc_d++;
+	if (getenv("BWB_DEBUG")) fprintf(stderr, "[bwb] k_calc_d class %d: %u reads, grid %u, %.3f ms\n", k, n_work, grid, ms);
 	return BWB_OK;
 }
 
@@ -329,18 +356,28 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	ScratchClass &s = c->cls[k];
 	Batch b = make_batch(c, wl, n_work);
 	OutBuf ob{ c->d_log, c->d_count, c->log_cap, c->d_off, c->d_n };
-	uint32_t o, l, sp, nb; size_t lds;
-	search_lds(c, o, l, sp, nb, lds);
+	const size_t lds = lane_lds(c);
 	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
-	const uint32_t grid = std::min<uint32_t>(s.blocks, (n_work + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK);
+	HIPCHK(hipMemsetAsync(c->d_pool_bump, 0, 4, c->stream)); /* every launch starts with an empty chunk pool */
+	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
-	hipLaunchKernelGGL(k_search, dim3(grid ? grid : 1), dim3(BWB_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats, o, l, sp, nb);
+	if (c->pos32 && !c->wide)
+		hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
+	else if (c->pos32)
+		hipLaunchKernelGGL((kl_search<uint32_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
+	else
+		hipLaunchKernelGGL((kl_search<uint64_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	float ms = 0;
 	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->stats.ms_search += ms; c->stats.launches_search++;
+	if (getenv("BWB_DEBUG")) {
+		unsigned int used = 0;
+		hipMemcpy(&used, c->d_pool_bump, 4, hipMemcpyDeviceToHost);
+		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, lds %zu B, %.3f ms, pool chunks used %u of %u\n", k, n_work, grid, lds, ms, used, s.sc.pool_cap);
+	}
 	return BWB_OK;
 }
 
@@ -411,6 +448,10 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	HIPCHK(hipMemcpy(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
 	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA];
 	c->stats.heap_pops = st[STAT_POPS]; c->stats.heap_pushes = st[STAT_PUSHES]; c->stats.n_alignments = st[STAT_ALNS];
+	if (getenv("BWB_DEBUG")) {
+		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu\n", st[STAT_N], st[STAT_N + 1]);
+		fprintf(stderr, "[bwb] stamps (cycles): top %llu | A(pop) %llu | B(issue) %llu | C(rank) %llu | D(act) %llu | E(exact) %llu | F(finish..) %llu\n", st[8+0], st[8+1], st[8+2], st[8+3], st[8+4], st[8+5], st[8+7]);
+	}
 	c->ran = true;
 	return BWB_OK;
 }
@@ -504,11 +545,15 @@ extern "C" int bwb_hip_rank_bench(bwb_hip_ctx *c, size_t n, int iters, uint64_t 
 	HIPCHK(hipSetDevice(c->device));
 	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
 	const unsigned grid = (unsigned)(c->num_cu * 8);
-	hipLaunchKernelGGL(k_rank_bench, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, seed, c->d_count); /* warm-up */
+	auto launch = [&](uint64_t sd) {
+		if (c->pos32) hipLaunchKernelGGL(k_rank_bench<uint32_t>, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, c->d_count);
+		else hipLaunchKernelGGL(k_rank_bench<uint64_t>, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, c->d_count);
+	};
+	launch(seed); /* warm-up */
 	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	for (int i = 0; i < iters; i++)
-		hipLaunchKernelGGL(k_rank_bench, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, seed + i, c->d_count);
+		launch(seed + i);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(c->ev1, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -547,5 +592,12 @@ extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, ui
 	HIPCHK(hipStreamSynchronize(c->stream));
 	HIPCHK(hipMemcpy(out_pos, dout, n * 8, hipMemcpyDeviceToHost));
 	hipFree(dr); hipFree(dout);
+	return BWB_OK;
+}
+
+/* developer aid (not in include/bwbble_hip.h): per-read loop iteration counts of the last batch_run when BWB_DEBUG_ITERS is set */
+extern "C" int bwb_hip_debug_iters(bwb_hip_ctx *c, uint32_t *out) {
+	if (!c || !c->d_dbg_iters) return fail(BWB_E_STATE, "debug iteration counts are off (set BWB_DEBUG_ITERS)");
+	HIPCHK(hipMemcpy(out, c->d_dbg_iters, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
 	return BWB_OK;
 }

@@ -10,6 +10,7 @@
  *            visit pair.
  *
  * One read per OCTET (8 lanes); everything "uniform" below is replicated in the 8 lanes.
+ * Kernels are templated on the position type P (uint32_t for BWT length < 2^32-1, else uint64_t).
  */
 #pragma once
 #include "bwb_device.h"
@@ -38,13 +39,14 @@ struct Batch {
 	uint32_t n_work;
 	uint32_t *counter;        /* work-stealing cursor */
 	uint8_t *status;          /* per read */
+	uint32_t *dbg_iters;      /* optional (BWB_DEBUG): loop iterations spent on each read */
 };
 
 struct Scratch {              /* per-octet private regions, slot = blockIdx.x*32 + octet */
 	uint4 *ent;               /* [slots][nchunks*16*2]  heap entries, 32 B each */
 	uint32_t *cprev;          /* [slots][nchunks]       chunk chain / free list */
 	uint4 *alns;              /* [slots][acap*2]        hits of the current read */
-	ulonglong2 *lists;        /* [slots][2*lcap]        SA-interval lists (cur/next) */
+	void *lists;              /* [slots][2*lcap]        SA-interval lists (cur/next) of Intv<P> */
 	uint32_t nchunks, acap, lcap;
 };
 
@@ -58,11 +60,18 @@ struct OutBuf {
 
 enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N };
 
+template <typename P> struct Intv { P L, U; };
+
 /* io.h:29,109: read base c (A0 G1 C2 T3) is compatible with code j iff gray(c) & grayVal[j]; N(10) excluded
  * (nucl_bases_table io.h:102-106).  Bit j of the mask = code j is a member. */
 __device__ __forceinline__ uint32_t member_mask(int c) {
 	/* A {8,9,11,12,13,14,15}  G {2,3,4,5,11,12,13}  C {4,5,6,7,8,9,11}  T {1,2,5,6,9,13,14} */
 	return c == 0 ? 0xFB00u : (c == 1 ? 0x383Cu : (c == 2 ? 0x0BF0u : 0x6266u));
+}
+
+template <typename P> __device__ __forceinline__ void load_base(P *s_base, const DevIndex &ix) {
+	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = (P)ix.base[t >> 4][t & 15];
+	__syncthreads();
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -72,26 +81,26 @@ __device__ __forceinline__ uint32_t member_mask(int c) {
  * ones in global memory (nlist[0..T-2]).  Returns the int-wrapped sum of child widths
  * (num_matches, inexact_match.c:227).
  * ------------------------------------------------------------------------------------------- */
-__device__ __forceinline__ int32_t append_children(uint64_t L0, uint64_t U0, uint64_t L1, uint64_t U1, bool ne0, bool ne1,
-                                                   int ol, int lane, volatile uint64_t *tail, ulonglong2 *nlist, int &T,
-                                                   int cap, bool &ovf) {
+template <typename P>
+__device__ __forceinline__ int32_t append_children(P L0, P U0, P L1, P U1, bool ne0, bool ne1, int ol, int lane,
+                                                   volatile P *tail, Intv<P> *nlist, int &T, int cap, bool &ovf) {
 	const uint32_t m16 = oct_or(((uint32_t)ne0 | ((uint32_t)ne1 << 1)) << (2 * ol));
 	uint32_t w = 0;
 	if (ne0) w += (uint32_t)(U0 - L0 + 1);
 	if (ne1) w += (uint32_t)(U1 - L1 + 1);
 	w = oct_add(w);
 	if (m16 == 0) return 0;
-	const uint64_t tL = tail[0], tU = tail[1];
+	const P tL = tail[0], tU = tail[1];
 	const uint32_t below0 = m16 & ((1u << (2 * ol)) - 1u);
-	const uint64_t lastU_mine = ne1 ? U1 : U0;
+	const P lastU_mine = ne1 ? U1 : U0;
 	const int p = below0 ? 31 - __clz((int)below0) : 0;
-	const uint64_t carryU = oct_bcast64(lastU_mine, (lane & ~7) + (p >> 1));
+	const P carryU = oct_bcast(lastU_mine, (lane & ~7) + (p >> 1));
 	const bool prev0 = below0 != 0 || T > 0;
-	const uint64_t prevU0 = below0 ? carryU : tU;
-	const bool new0 = ne0 && !(prev0 && L0 == prevU0 + 1);
+	const P prevU0 = below0 ? carryU : tU;
+	const bool new0 = ne0 && !(prev0 && L0 == (P)(prevU0 + 1));
 	const bool prev1 = ne0 || prev0;
-	const uint64_t prevU1 = ne0 ? U0 : prevU0;
-	const bool new1 = ne1 && !(prev1 && L1 == prevU1 + 1);
+	const P prevU1 = ne0 ? U0 : prevU0;
+	const bool new1 = ne1 && !(prev1 && L1 == (P)(prevU1 + 1));
 	const uint32_t n16 = oct_or(((uint32_t)new0 | ((uint32_t)new1 << 1)) << (2 * ol));
 	const int total_new = __popc(n16);
 	const int newT = T + total_new;
@@ -101,7 +110,7 @@ __device__ __forceinline__ int32_t append_children(uint64_t L0, uint64_t U0, uin
 #pragma unroll
 	for (int h = 0; h < 2; h++) {
 		const bool ne = h ? ne1 : ne0, nw = h ? new1 : new0;
-		const uint64_t L = h ? L1 : L0, U = h ? U1 : U0;
+		const P L = h ? L1 : L0, U = h ? U1 : U0;
 		const int k = 2 * ol + h;
 		if (ne) {
 			const uint32_t upto = (2u << k) - 1u;
@@ -112,14 +121,13 @@ __device__ __forceinline__ int32_t append_children(uint64_t L0, uint64_t U0, uin
 				if (nw) tail[0] = L;
 				if (last) tail[1] = U;
 			} else {
-				unsigned long long *slot = (unsigned long long *)&nlist[idx];
-				if (nw) slot[0] = L;
-				if (last) { slot[1] = U; if (cont && idx == T - 1) slot[0] = tL; }
+				if (nw) nlist[idx].L = L;
+				if (last) { nlist[idx].U = U; if (cont && idx == T - 1) nlist[idx].L = tL; }
 			}
 		}
 	}
 	/* old tail closed unchanged because the first child starts a new run */
-	if (T > 0 && !cont && ol == (firstk >> 1)) nlist[T - 1] = make_ulonglong2(tL, tU);
+	if (T > 0 && !cont && ol == (firstk >> 1)) { nlist[T - 1].L = tL; nlist[T - 1].U = tU; }
 	T = newT;
 	return (int32_t)w;
 }
@@ -128,7 +136,7 @@ __device__ __forceinline__ int32_t append_children(uint64_t L0, uint64_t U0, uin
 __device__ __forceinline__ uint32_t next_read(const Batch &b, int ol, int lane) {
 	uint32_t w = 0;
 	if (ol == 0) w = atomicAdd(b.counter, 1u);
-	w = __shfl(w, lane & ~7);
+	w = oct_bcast(w, lane & ~7);
 	if (w >= b.n_work) return NONE32;
 	return b.worklist ? b.worklist[w] : w;
 }
@@ -136,22 +144,24 @@ __device__ __forceinline__ uint32_t next_read(const Batch &b, int ol, int lane) 
 /* ============================================================================================
  * k_calc_d
  * ========================================================================================== */
+template <typename P>
 __global__ __launch_bounds__(BWB_BLOCK) void k_calc_d(DevIndex ix, Batch b, KParams kp, Scratch sc, int32_t *dbgD,
                                                       int32_t *dbgDs, uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
-	uint64_t *s_base = (uint64_t *)smem;                                  /* BWB_BASE_ROWS*16 */
-	volatile uint64_t *s_tail = (volatile uint64_t *)(s_base + BWB_BASE_ROWS * 16); /* [32][4] */
-	volatile uint8_t *s_seq = (volatile uint8_t *)(s_base + BWB_BASE_ROWS * 16 + BWB_OCTS_PER_BLOCK * 4); /* [32][spad] */
+	P *s_base = (P *)smem;                                                          /* BWB_BASE_ROWS*16 */
+	volatile P *s_tail = (volatile P *)(smem + BWB_BASE_ROWS * 16 * 8);             /* [32][4] */
+	volatile uint8_t *s_seq = (volatile uint8_t *)(smem + BWB_BASE_ROWS * 16 * 8 + BWB_OCTS_PER_BLOCK * 4 * 8); /* [32][spad] */
 	const uint32_t spad = (b.stride + 15u) & ~15u;
-	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = ix.base[t >> 4][t & 15];
-	__syncthreads();
+	load_base<P>(s_base, ix);
 
 	const int lane = threadIdx.x & 63, ol = lane & 7, ob = threadIdx.x >> 3;
 	const uint32_t slot = blockIdx.x * BWB_OCTS_PER_BLOCK + ob;
-	volatile uint64_t *tails = s_tail + ob * 4;
+	volatile P *tails = s_tail + ob * 4;
 	volatile uint8_t *sseq = s_seq + ob * spad;
-	ulonglong2 *lbase = sc.lists + (size_t)slot * 2 * sc.lcap;
+	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
 	const int cap = (int)sc.lcap;
+	const uint4 *__restrict__ buckets = ix.buckets;
+	const P last_row = (P)(ix.length - 1);
 
 	bool active = false, done = false;
 	uint32_t rid = 0;
@@ -167,10 +177,10 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_calc_d(DevIndex ix, Batch b, KPar
 				len = b.lens[rid];
 				for (int k = ol; k < len; k += 8) sseq[k] = b.reads[(size_t)rid * b.stride + k];
 				phase = 0; plen = len; r = len - 1; z = 0; s = 0; T = 0; cursel = 0; nm = 0; prev_nm = 0;
-				if (ol == 0) { tails[0] = 0; tails[1] = ix.length - 1; }
+				tails[0] = 0; tails[1] = last_row;
 				curT = 1;
 				active = len > 0;
-				if (!active) b.status[rid] = ST_OK;
+				if (!active && ol == 0) b.status[rid] = ST_OK;
 			}
 		}
 		if (__all(done)) break;
@@ -179,21 +189,22 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_calc_d(DevIndex ix, Batch b, KPar
 			bool ovf = false;
 			if (c <= 3) {
 				/* interval s of the current list */
-				uint64_t iL, iU;
+				P iL, iU;
 				if (s == curT - 1) { iL = tails[cursel * 2]; iU = tails[cursel * 2 + 1]; }
-				else { const ulonglong2 v = (lbase + cursel * cap)[s]; iL = v.x; iU = v.y; }
-				RankReq ra, rb;
-				rank_issue(ix, iL - 1, ol, ra);
-				rank_issue(ix, iU, ol, rb);
+				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
+				RankReq<P> ra, rb;
+				rank_issue<P>(buckets, last_row, (P)(iL - 1), ol, ra);
+				rank_issue<P>(buckets, last_row, iU, ol, rb);
 				vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
-				uint64_t a0, a1, u0, u1;
-				rank_finish(ra, s_base, ol, lane, false, a0, a1);
-				rank_finish(rb, s_base, ol, lane, false, u0, u1);
+				P a0, a1, u0, u1;
+				rank_finish<P, false>(ra, s_base, ol, lane, a0, a1);
+				rank_finish<P, false>(rb, s_base, ol, lane, u0, u1);
 				const uint32_t mem = member_mask(c);
-				const bool ne0 = ((mem >> (2 * ol)) & 1u) && (a0 + 1 <= u0);
-				const bool ne1 = ((mem >> (2 * ol + 1)) & 1u) && (a1 + 1 <= u1);
-				nm += append_children(a0 + 1, u0, a1 + 1, u1, ne0, ne1, ol, lane, tails + (cursel ^ 1) * 2,
-				                      lbase + (cursel ^ 1) * cap, T, cap, ovf);
+				const P L0 = a0 + 1, L1 = a1 + 1;
+				const bool ne0 = ((mem >> (2 * ol)) & 1u) && (L0 <= u0);
+				const bool ne1 = ((mem >> (2 * ol + 1)) & 1u) && (L1 <= u1);
+				nm += append_children<P>(L0, u0, L1, u1, ne0, ne1, ol, lane, tails + (cursel ^ 1) * 2,
+				                         lbase + (cursel ^ 1) * cap, T, cap, ovf);
 				s++;
 			}
 			if (ovf) {
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_calc_d(DevIndex ix, Batch b, KPar
 				/* position finished: swap lists (inexact_match.c:234-237) */
 				cursel ^= 1; curT = (c > 3) ? 0 : T; T = 0; s = 0;
 				if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
-					if (ol == 0) { tails[cursel * 2] = 0; tails[cursel * 2 + 1] = ix.length - 1; }
+					tails[cursel * 2] = 0; tails[cursel * 2 + 1] = last_row;
 					curT = 1; z++;
 					nm = (int32_t)(uint32_t)ix.length;
 				}
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_calc_d(DevIndex ix, Batch b, KPar
 					}
 					if (phase == 0 && kp.seed_length && len > kp.seed_length) { /* inexact_match.c:141-143 */
 						phase = 1; plen = kp.seed_length; r = plen - 1; z = 0; prev_nm = 0;
-						if (ol == 0) { tails[cursel * 2] = 0; tails[cursel * 2 + 1] = ix.length - 1; }
+						tails[cursel * 2] = 0; tails[cursel * 2 + 1] = last_row;
 						curT = 1;
 					} else {
 						if (ol == 0) b.status[rid] = ST_OK;
@@ -236,7 +247,6 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_calc_d(DevIndex ix, Batch b, KPar
 	}
 	if (ol == 0 && vis) atomicAdd(&stats[STAT_VIS_SINGLE], vis);
 }
-
 
 /* ============================================================================================
  * k_search
@@ -289,19 +299,19 @@ __device__ __forceinline__ size_t resv_slot(const Resv &r, int t) {
 	return (size_t)c * 16 + (p & 15);
 }
 
+template <typename P>
 __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KParams kp, Scratch sc, OutBuf out,
                                                       unsigned long long *stats, uint32_t lds_oct_bytes, uint32_t lpad,
                                                       uint32_t spadseed, uint32_t nbpad) {
 	extern __shared__ __align__(16) unsigned char smem[];
-	uint64_t *s_base = (uint64_t *)smem;
-	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = ix.base[t >> 4][t & 15];
-	__syncthreads();
+	P *s_base = (P *)smem;
+	load_base<P>(s_base, ix);
 
 	const int lane = threadIdx.x & 63, ol = lane & 7, obk = threadIdx.x >> 3;
 	const uint32_t slot = blockIdx.x * BWB_OCTS_PER_BLOCK + obk;
-	/* per-octet LDS: tails[4] u64 | bstate[nbpad] u32 | D[lpad] | Dseed[spadseed] | rc[lpad] */
+	/* per-octet LDS: tails[4] (32 B) | bstate[nbpad] u32 | D[lpad] | Dseed[spadseed] | rc[lpad] */
 	unsigned char *my = smem + BWB_BASE_ROWS * 16 * 8 + (size_t)obk * lds_oct_bytes;
-	volatile uint64_t *tails = (volatile uint64_t *)my;
+	volatile P *tails = (volatile P *)my;
 	volatile uint32_t *bstate = (volatile uint32_t *)(my + 32);
 	volatile uint8_t *sD = (volatile uint8_t *)(my + 32 + 4 * nbpad);
 	volatile uint8_t *sDs = sD + lpad;
@@ -310,9 +320,11 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 	uint4 *ent = sc.ent + (size_t)slot * sc.nchunks * 32;
 	uint32_t *cprev = sc.cprev + (size_t)slot * sc.nchunks;
 	uint4 *myalns = sc.alns + (size_t)slot * sc.acap * 2;
-	ulonglong2 *lbase = sc.lists + (size_t)slot * 2 * sc.lcap;
+	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
+	const uint4 *__restrict__ buckets = ix.buckets;
+	const P last_row = (P)(ix.length - 1);
 
 	bool active = false, done = false;
 	uint32_t rid = 0;
@@ -320,7 +332,8 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 	Heap h; h.bump = 0; h.fhead = NONE32; h.neLo = h.neHi = 0; h.best = nb; h.num_entries = 0;
 	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
 	int r = 0, s = 0, curT = 0, T = 0, cursel = 0;               /* exact-tail state */
-	uint64_t eL = 0, eU = 0, eruns = ~0ull;                       /* popped entry */
+	P eL = 0, eU = 0;                                             /* popped entry */
+	uint32_t erunsLo = ~0u, erunsHi = ~0u;
 	int e_i = 0, e_mm = 0, e_go = 0, e_ge = 0, e_state = 0, e_alen = 0, e_score = 0;
 	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
 
@@ -365,16 +378,16 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 		if (!active) continue;
 
 		bool finish = false, ovf = false, expanding = false, exact_iter = false, exact_done = false;
-		uint64_t iL = 0, iU = 0;
+		P iL = 0, iU = 0;
 
 		/* add_alignment (align.c:271-298) into the octet's private hit list */
-		auto add_aln = [&](uint64_t L, uint64_t U, int score, int alen) {
+		auto add_aln = [&](P L, P U, int score, int alen) {
 			bool dup = false;
 			if (e_go) {
 				uint32_t hit = 0;
 				for (int j = ol; j < n_alns; j += 8) {
 					const uint4 a = myalns[j * 2];
-					hit |= (a.x == (uint32_t)L && a.y == (uint32_t)(L >> 32) && a.z == (uint32_t)U && a.w == (uint32_t)(U >> 32)) ? 1u : 0u;
+					hit |= (a.x == (uint32_t)L && a.y == (uint32_t)((uint64_t)L >> 32) && a.z == (uint32_t)U && a.w == (uint32_t)((uint64_t)U >> 32)) ? 1u : 0u;
 				}
 				dup = oct_or(hit) != 0;
 			}
@@ -382,9 +395,9 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 				if (n_alns >= (int)sc.acap) ovf = true;
 				else {
 					if (ol == 0) {
-						myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)(L >> 32), (uint32_t)U, (uint32_t)(U >> 32));
+						myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
 						myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 255) | (e_mm << 8) | (e_go << 16) | (e_ge << 24),
-						                                    (uint32_t)(alen & 255), (uint32_t)eruns, (uint32_t)(eruns >> 32));
+						                                    (uint32_t)(alen & 255), erunsLo, erunsHi);
 					}
 					n_alns++;
 				}
@@ -413,10 +426,10 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 				} else bstate[bk] = (chunk << 5) | (uint32_t)(fill - 1);
 				h.num_entries--; n_pop++;
 				e_score = bk;
-				eL = ((uint64_t)w0.y << 32) | w0.x; eU = ((uint64_t)w0.w << 32) | w0.z;
+				eL = (P)(((uint64_t)w0.y << 32) | w0.x); eU = (P)(((uint64_t)w0.w << 32) | w0.z);
 				e_i = w1.x & 255; e_mm = (w1.x >> 8) & 255; e_go = (w1.x >> 16) & 255; e_ge = (w1.x >> 24) & 255;
 				e_state = w1.y & 3; e_alen = (w1.y >> 8) & 255;
-				eruns = ((uint64_t)w1.w << 32) | w1.z;
+				erunsLo = w1.z; erunsHi = w1.w;
 
 				if (e_score > best_score + kp.mm_score) finish = true; /* :309 */
 				else {
@@ -452,125 +465,136 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 			if (c > 3) { curT = 0; exact_done = true; } /* :84-87 */
 			else {
 				if (s == curT - 1) { iL = tails[cursel * 2]; iU = tails[cursel * 2 + 1]; }
-				else { const ulonglong2 v = (lbase + cursel * lcap)[s]; iL = v.x; iU = v.y; }
+				else { const Intv<P> v = (lbase + cursel * lcap)[s]; iL = v.L; iU = v.U; }
 				exact_iter = true;
 			}
 		}
 
-		if (expanding || exact_iter) {
-			RankReq ra, rb;
-			rank_issue(ix, iL - 1, ol, ra);
-			rank_issue(ix, iU, ol, rb);
-			const int nvis = (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
-			uint64_t a0, a1, u0, u1;
-			rank_finish(ra, s_base, ol, lane, expanding, a0, a1);
-			rank_finish(rb, s_base, ol, lane, expanding, u0, u1);
-			const uint64_t L0 = a0 + 1, L1 = a1 + 1; /* inc = 1 on the L side (:382) */
-			if (exact_iter) {
-				vis_s += nvis;
-				const uint32_t mem = member_mask(c);
-				const bool ne0 = ((mem >> (2 * ol)) & 1u) && (L0 <= u0);
-				const bool ne1 = ((mem >> (2 * ol + 1)) & 1u) && (L1 <= u1);
-				append_children(L0, u0, L1, u1, ne0, ne1, ol, lane, tails + (cursel ^ 1) * 2, lbase + (cursel ^ 1) * lcap, T, lcap, ovf);
-				s++;
-				if (!ovf && s >= curT) {
-					cursel ^= 1; curT = T; T = 0; s = 0;
-					if (curT == 0) exact_done = true; /* :114 */
-					else { r--; if (r < 0) exact_done = true; }
-				}
+		if (exact_iter) {
+			RankReq<P> ra, rb;
+			rank_issue<P>(buckets, last_row, (P)(iL - 1), ol, ra);
+			rank_issue<P>(buckets, last_row, iU, ol, rb);
+			vis_s += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
+			P a0, a1, u0, u1;
+			rank_finish<P, false>(ra, s_base, ol, lane, a0, a1);
+			rank_finish<P, false>(rb, s_base, ol, lane, u0, u1);
+			const P L0 = a0 + 1, L1 = a1 + 1;
+			const uint32_t mem = member_mask(c);
+			const bool ne0 = ((mem >> (2 * ol)) & 1u) && (L0 <= u0);
+			const bool ne1 = ((mem >> (2 * ol + 1)) & 1u) && (L1 <= u1);
+			append_children<P>(L0, u0, L1, u1, ne0, ne1, ol, lane, tails + (cursel ^ 1) * 2, lbase + (cursel ^ 1) * lcap, T, lcap, ovf);
+			s++;
+			if (!ovf && s >= curT) {
+				cursel ^= 1; curT = T; T = 0; s = 0;
+				if (curT == 0) exact_done = true; /* :114 */
+				else { r--; if (r < 0) exact_done = true; }
+			}
+		} else if (expanding) {
+			RankReq<P> ra, rb;
+			rank_issue<P>(buckets, last_row, (P)(iL - 1), ol, ra);
+			rank_issue<P>(buckets, last_row, iU, ol, rb);
+			vis_a += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
+			/* ---- allow_* flags :392-430 (uniform; computed while the bucket loads are in flight) ---- */
+			const int diff_left = max_diff - e_mm - e_go - e_ge;
+			const int diff_left_seed = kp.max_diff_seed - e_mm - e_go - e_ge;
+			const int seed_index = e_i - (len - kp.seed_length);
+			bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
+			if (e_i - 1 > 0) {
+				const int d1 = sD[e_i - 1], d2 = sD[e_i - 2];
+				if ((diff_left - 1) < (d2 & 127)) allow_diff = false;
+				else if ((d1 & 127) == diff_left - 1 && (d2 & 127) == diff_left - 1 && (d1 & 128)) allow_mm = false;
+			}
+			if (seed_index - 1 > 0) {
+				const int d1 = sDs[seed_index - 1], d2 = sDs[seed_index - 2];
+				if ((diff_left_seed - 1) < (d2 & 127)) allow_diff = false;
+				else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
+			}
+			const int tmp = e_go + e_ge;
+			if ((e_i - 1 < kp.no_indel_length + tmp) || ((len - (e_i - 1)) < kp.no_indel_length + tmp)) allow_indels = false;
+			if (e_go >= kp.max_gapo && e_ge >= kp.max_gape) allow_indels = false;
+			if (e_go >= kp.max_gapo) allow_open = false;
+			if (e_ge >= kp.max_gape) allow_extend = false;
+			const int cr = src[e_i - 1];
+			const bool gap_open = e_state == STATE_M;
+			const int sc0 = e_score, scX = e_score + kp.mm_score, scG = e_score + (gap_open ? kp.gapo_score : kp.gape_score);
+			const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
+			const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
+			const bool mm_ok = allow_diff && allow_mm;
+			const uint32_t mem = cr > 3 ? 0u : member_mask(cr);
+			/* uniform parts of the child entries */
+			const uint32_t alen1 = (uint32_t)((e_alen + 1) & 255);
+			const uint32_t w1x_base = ((uint32_t)e_go << 16) | ((uint32_t)e_ge << 24);
+			const uint32_t w1x_match = (uint32_t)((e_i - 1) & 255) | ((uint32_t)e_mm << 8) | w1x_base;
+			const uint32_t w1x_mis = (uint32_t)((e_i - 1) & 255) | ((uint32_t)((e_mm + 1) & 255) << 8) | w1x_base;
+			const uint32_t w1x_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
+			/* gap runs of a gap child: new run on open (start = aln_length, len 1), len+1 on extend */
+			const uint64_t eruns = ((uint64_t)erunsHi << 32) | erunsLo;
+			uint64_t gruns_i, gruns_d;
+			if (gap_open) {
+				const int sh = 16 * (e_go & 3);
+				const uint64_t cleared = eruns & ~(0xFFFFull << sh);
+				gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
+				gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
 			} else {
-				vis_a += nvis;
-				/* ---- expansion :392-504 ---- */
-				const int diff_left = max_diff - e_mm - e_go - e_ge;
-				const int diff_left_seed = kp.max_diff_seed - e_mm - e_go - e_ge;
-				const int seed_index = e_i - (len - kp.seed_length);
-				bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
-				if (e_i - 1 > 0) {
-					const int d1 = sD[e_i - 1], d2 = sD[e_i - 2];
-					if ((diff_left - 1) < (d2 & 127)) allow_diff = false;
-					else if ((d1 & 127) == diff_left - 1 && (d2 & 127) == diff_left - 1 && (d1 & 128)) allow_mm = false;
-				}
-				if (seed_index - 1 > 0) {
-					const int d1 = sDs[seed_index - 1], d2 = sDs[seed_index - 2];
-					if ((diff_left_seed - 1) < (d2 & 127)) allow_diff = false;
-					else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
-				}
-				const int tmp = e_go + e_ge;
-				if ((e_i - 1 < kp.no_indel_length + tmp) || ((len - (e_i - 1)) < kp.no_indel_length + tmp)) allow_indels = false;
-				if (e_go >= kp.max_gapo && e_ge >= kp.max_gape) allow_indels = false;
-				if (e_go >= kp.max_gapo) allow_open = false;
-				if (e_ge >= kp.max_gape) allow_extend = false;
+				gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
+			}
 
-				const int cr = src[e_i - 1];
-				const bool gap_open = e_state == STATE_M;
-				const int sc0 = e_score, scX = e_score + kp.mm_score, scG = e_score + (gap_open ? kp.gapo_score : kp.gape_score);
-				const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
-				const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
-				const bool mm_ok = allow_diff && allow_mm;
-				const uint32_t mem = cr > 3 ? 0u : member_mask(cr);
-				const int j0 = 2 * ol, j1 = 2 * ol + 1;
-				const bool ne0 = j0 >= 1 && L0 <= u0, ne1 = L1 <= u1;
-				const bool mb0 = (mem >> j0) & 1u, mb1 = (mem >> j1) & 1u;
-				/* push sequence (:434-504): bit 0 insertion, bits 1..15 deletions j, bits 16+j match/mismatch j */
-				const bool g0 = j0 == 0 ? ins_ok : (del_ok && ne0), g1 = del_ok && ne1;
-				const bool ma0 = ne0 && mb0, ma1 = ne1 && mb1;
-				const bool mi0 = mm_ok && ne0 && !mb0, mi1 = mm_ok && ne1 && !mb1;
-				const uint32_t Mgm = oct_or((((uint32_t)g0 | ((uint32_t)g1 << 1)) << j0) | (((uint32_t)ma0 | ((uint32_t)ma1 << 1)) << (16 + j0)));
-				const uint32_t Mx = oct_or(((uint32_t)mi0 | ((uint32_t)mi1 << 1)) << (16 + j0));
-				const uint32_t Mg = Mgm & 0xFFFFu, Mm = Mgm & 0xFFFF0000u;
-				/* up to three target buckets; classes that share a score share a bucket in sequence order */
-				const uint32_t mA = Mm | (scX == sc0 ? Mx : 0u) | (scG == sc0 ? Mg : 0u);
-				const uint32_t mB = scX != sc0 ? (Mx | (scG == scX ? Mg : 0u)) : 0u;
-				const uint32_t mC = (scG != sc0 && scG != scX) ? Mg : 0u;
-				Resv rA = { 0, 0, 0, 0 }, rB = { 0, 0, 0, 0 }, rC = { 0, 0, 0, 0 };
-				if (mA) rA = heap_reserve(h, sc0, __popc(mA), bstate, cprev, sc.nchunks, ol, ovf);
-				if (mB && !ovf) rB = heap_reserve(h, scX, __popc(mB), bstate, cprev, sc.nchunks, ol, ovf);
-				if (mC && !ovf) rC = heap_reserve(h, scG, __popc(mC), bstate, cprev, sc.nchunks, ol, ovf);
-				if (!ovf) {
-					n_push += __popc(mA) + __popc(mB) + __popc(mC);
-					const uint32_t alen1 = (uint32_t)((e_alen + 1) & 255);
-					/* gap runs of the child (one 16-bit run per gap open) */
-					uint64_t gruns = eruns;
-					int g_go = e_go, g_ge = e_ge;
-					if (gap_open) { g_go = e_go + 1; }
-					else { g_ge = e_ge + 1; }
+			P a0, a1, u0, u1;
+			rank_finish<P, true>(ra, s_base, ol, lane, a0, a1);
+			rank_finish<P, true>(rb, s_base, ol, lane, u0, u1);
+			const P L0 = a0 + 1, L1 = a1 + 1; /* inc = 1 on the L side (:382) */
+			const int j0 = 2 * ol, j1 = 2 * ol + 1;
+			const bool ne0 = j0 >= 1 && L0 <= u0, ne1 = L1 <= u1;
+			const bool mb0 = (mem >> j0) & 1u, mb1 = (mem >> j1) & 1u;
+			/* push sequence (:434-504): bit 0 insertion, bits 1..15 deletions j, bits 16+j match/mismatch j */
+			const bool g0 = j0 == 0 ? ins_ok : (del_ok && ne0), g1 = del_ok && ne1;
+			const bool ma0 = ne0 && mb0, ma1 = ne1 && mb1;
+			const bool mi0 = mm_ok && ne0 && !mb0, mi1 = mm_ok && ne1 && !mb1;
+			const uint32_t Mgm = oct_or((((uint32_t)g0 | ((uint32_t)g1 << 1)) << j0) | (((uint32_t)ma0 | ((uint32_t)ma1 << 1)) << (16 + j0)));
+			const uint32_t Mx = oct_or(((uint32_t)mi0 | ((uint32_t)mi1 << 1)) << (16 + j0));
+			const uint32_t Mg = Mgm & 0xFFFFu, Mm = Mgm & 0xFFFF0000u;
+			/* up to three target buckets; classes that share a score share a bucket in sequence order */
+			const uint32_t mA = Mm | (scX == sc0 ? Mx : 0u) | (scG == sc0 ? Mg : 0u);
+			const uint32_t mB = scX != sc0 ? (Mx | (scG == scX ? Mg : 0u)) : 0u;
+			const uint32_t mC = (scG != sc0 && scG != scX) ? Mg : 0u;
+			Resv rA = { 0, 0, 0, 0 }, rB = { 0, 0, 0, 0 }, rC = { 0, 0, 0, 0 };
+			if (mA) rA = heap_reserve(h, sc0, __popc(mA), bstate, cprev, sc.nchunks, ol, ovf);
+			if (mB && !ovf) rB = heap_reserve(h, scX, __popc(mB), bstate, cprev, sc.nchunks, ol, ovf);
+			if (mC && !ovf) rC = heap_reserve(h, scG, __popc(mC), bstate, cprev, sc.nchunks, ol, ovf);
+			if (!ovf) {
+				n_push += __popc(mA) + __popc(mB) + __popc(mC);
+				/* the lane's own four possible pushes: deletion/insertion for j0, j1; match/mismatch for j0, j1 */
 #pragma unroll
-					for (int hh = 0; hh < 4; hh++) {
-						const bool isgap = hh < 2;
-						const int hsel = hh & 1;
-						const bool valid = isgap ? (hsel ? g1 : g0) : (hsel ? (ma1 || mi1) : (ma0 || mi0));
-						if (valid) {
-							const int j = hsel ? j1 : j0;
-							const bool is_mis = !isgap && (hsel ? mi1 : mi0);
-							const int q = isgap ? j : 16 + j;
-							const int spush = isgap ? scG : (is_mis ? scX : sc0);
-							const uint32_t below = (q == 0) ? 0u : ((q >= 32) ? 0xFFFFFFFFu : ((1u << q) - 1u));
-							size_t sl;
-							if (spush == sc0) sl = resv_slot(rA, __popc(mA & below));
-							else if (spush == scX) sl = resv_slot(rB, __popc(mB & below));
-							else sl = resv_slot(rC, __popc(mC & below));
-							const bool is_ins = isgap && j == 0;
-							uint64_t cL = hsel ? L1 : L0, cU = hsel ? u1 : u0;
-							if (is_ins) { cL = eL; cU = eU; }
-							int ci = (isgap && !is_ins) ? e_i : e_i - 1;
-							int cmm = e_mm + (is_mis ? 1 : 0), cgo = isgap ? g_go : e_go, cge = isgap ? g_ge : e_ge;
-							int cstate = isgap ? (is_ins ? STATE_I : STATE_D) : STATE_M;
-							uint64_t cruns = eruns;
-							if (isgap) {
-								if (gap_open) {
-									const uint64_t run = (uint64_t)((uint32_t)e_alen | (1u << 8) | (is_ins ? 0u : 0x8000u));
-									const int sh = 16 * (e_go & 3);
-									cruns = (eruns & ~(0xFFFFull << sh)) | (run << sh);
-								} else {
-									const int sh = 16 * ((e_go - 1) & 3);
-									cruns = eruns + (0x100ull << sh);
-								}
-							}
-							(void)gruns;
-							ent[sl * 2] = make_uint4((uint32_t)cL, (uint32_t)(cL >> 32), (uint32_t)cU, (uint32_t)(cU >> 32));
-							ent[sl * 2 + 1] = make_uint4((uint32_t)(ci & 255) | ((cmm & 255) << 8) | ((cgo & 255) << 16) | ((uint32_t)(cge & 255) << 24),
-							                             (uint32_t)cstate | (alen1 << 8), (uint32_t)cruns, (uint32_t)(cruns >> 32));
+				for (int hh = 0; hh < 4; hh++) {
+					const bool isgap = hh < 2;
+					const int hsel = hh & 1;
+					const bool valid = isgap ? (hsel ? g1 : g0) : (hsel ? (ma1 || mi1) : (ma0 || mi0));
+					if (valid) {
+						const int j = hsel ? j1 : j0;
+						const bool is_mis = !isgap && (hsel ? mi1 : mi0);
+						const int q = isgap ? j : 16 + j;
+						const int spush = isgap ? scG : (is_mis ? scX : sc0);
+						const uint32_t below = (1u << q) - 1u; /* q <= 31 */
+						size_t sl;
+						if (spush == sc0) sl = resv_slot(rA, __popc(mA & below));
+						else if (spush == scX) sl = resv_slot(rB, __popc(mB & below));
+						else sl = resv_slot(rC, __popc(mC & below));
+						const bool is_ins = isgap && j == 0;
+						P cL = hsel ? L1 : L0, cU = hsel ? u1 : u0;
+						if (is_ins) { cL = eL; cU = eU; }
+						uint32_t w1x, w1y, rl, rh;
+						if (isgap) {
+							w1x = w1x_gap | (uint32_t)((is_ins ? e_i - 1 : e_i) & 255);
+							w1y = (is_ins ? STATE_I : STATE_D) | (alen1 << 8);
+							const uint64_t gr = is_ins ? gruns_i : gruns_d;
+							rl = (uint32_t)gr; rh = (uint32_t)(gr >> 32);
+						} else {
+							w1x = is_mis ? w1x_mis : w1x_match;
+							w1y = STATE_M | (alen1 << 8);
+							rl = erunsLo; rh = erunsHi;
 						}
+						ent[sl * 2] = make_uint4((uint32_t)cL, (uint32_t)((uint64_t)cL >> 32), (uint32_t)cU, (uint32_t)((uint64_t)cU >> 32));
+						ent[sl * 2 + 1] = make_uint4(w1x, w1y, rl, rh);
 					}
 				}
 			}
@@ -587,9 +611,9 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 				bool brk = false;
 				if (e_score == best_score) {
 					for (int k = 0; k < curT; k++) {
-						uint64_t L, U;
+						P L, U;
 						if (k == curT - 1) { L = tails[cursel * 2]; U = tails[cursel * 2 + 1]; }
-						else { const ulonglong2 v = (lbase + cursel * lcap)[k]; L = v.x; U = v.y; }
+						else { const Intv<P> v = (lbase + cursel * lcap)[k]; L = v.L; U = v.U; }
 						num_best += (int)(uint32_t)(U - L + 1);
 					}
 				} else if (num_best > kp.max_best) brk = true;
@@ -597,9 +621,9 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 				else {
 					const int alen2 = (e_alen + e_i) & 255; /* :365 */
 					for (int k = 0; k < curT && !ovf; k++) {
-						uint64_t L, U;
+						P L, U;
 						if (k == curT - 1) { L = tails[cursel * 2]; U = tails[cursel * 2 + 1]; }
-						else { const ulonglong2 v = (lbase + cursel * lcap)[k]; L = v.x; U = v.y; }
+						else { const Intv<P> v = (lbase + cursel * lcap)[k]; L = v.L; U = v.U; }
 						add_aln(L, U, e_score, alen2);
 					}
 				}
@@ -612,7 +636,7 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_search(DevIndex ix, Batch b, KPar
 			bool outovf = false;
 			if (!ovf && n_alns > 0) {
 				if (ol == 0) off = atomicAdd(out.count, (unsigned long long)n_alns);
-				off = oct_bcast64(off, lane & ~7);
+				off = oct_bcast((uint64_t)off, lane & ~7);
 				if (off + (unsigned long long)n_alns > out.cap) outovf = true;
 				else for (int t = ol; t < n_alns * 2; t += 8) out.alns[off * 2 + t] = myalns[t];
 			}
@@ -679,41 +703,41 @@ __global__ void k_relayout(const uint32_t *bwt, const uint64_t *O, uint64_t blk0
 /* O_alphabet / exact Occ16 for a list of positions: one octet per query */
 __global__ __launch_bounds__(BWB_BLOCK) void k_rank16(DevIndex ix, const uint64_t *pos, uint64_t n, int inc, int exact, uint64_t *out) {
 	__shared__ uint64_t s_base[BWB_BASE_ROWS * 16];
-	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = ix.base[t >> 4][t & 15];
-	__syncthreads();
+	load_base<uint64_t>(s_base, ix);
 	const int lane = threadIdx.x & 63, ol = lane & 7;
 	const uint64_t noct = (uint64_t)gridDim.x * BWB_OCTS_PER_BLOCK;
 	for (uint64_t q = (uint64_t)blockIdx.x * BWB_OCTS_PER_BLOCK + (threadIdx.x >> 3); q < n; q += noct) {
-		RankReq ra;
-		rank_issue(ix, pos[q], ol, ra);
+		RankReq<uint64_t> ra;
+		rank_issue<uint64_t>(ix.buckets, ix.length - 1, pos[q], ol, ra);
 		uint64_t v0, v1;
-		rank_finish(ra, s_base, ol, lane, !exact, v0, v1);
+		if (exact) rank_finish<uint64_t, false>(ra, s_base, ol, lane, v0, v1);
+		else rank_finish<uint64_t, true>(ra, s_base, ol, lane, v0, v1);
 		out[q * 16 + 2 * ol] = ol == 0 ? 0 : v0 + inc;
 		out[q * 16 + 2 * ol + 1] = v1 + inc;
 	}
 }
 
 /* Rank micro-benchmark: pseudo-random positions, 4 independent visits in flight per octet */
+template <typename P>
 __global__ __launch_bounds__(BWB_BLOCK) void k_rank_bench(DevIndex ix, uint64_t n, uint64_t seed, unsigned long long *checksum) {
-	__shared__ uint64_t s_base[BWB_BASE_ROWS * 16];
-	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = ix.base[t >> 4][t & 15];
-	__syncthreads();
+	__shared__ P s_base[BWB_BASE_ROWS * 16];
+	load_base<P>(s_base, ix);
 	const int lane = threadIdx.x & 63, ol = lane & 7;
 	const uint64_t noct = (uint64_t)gridDim.x * BWB_OCTS_PER_BLOCK;
 	unsigned long long acc = 0;
 	for (uint64_t q = ((uint64_t)blockIdx.x * BWB_OCTS_PER_BLOCK + (threadIdx.x >> 3)) * 4; q < n; q += noct * 4) {
-		RankReq rq[4];
+		RankReq<P> rq[4];
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			uint64_t x = (q + u) * 0x9E3779B97F4A7C15ull + seed;
 			x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-			rank_issue(ix, x % (ix.length - 1), ol, rq[u]);
+			rank_issue<P>(ix.buckets, (P)(ix.length - 1), (P)(x % (ix.length - 1)), ol, rq[u]);
 		}
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
-			uint64_t v0, v1;
-			rank_finish(rq[u], s_base, ol, lane, false, v0, v1);
-			acc += v0 + 3 * v1;
+			P v0, v1;
+			rank_finish<P, false>(rq[u], s_base, ol, lane, v0, v1);
+			acc += (unsigned long long)v0 + 3ull * v1;
 		}
 	}
 	acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
@@ -733,26 +757,25 @@ __global__ void k_gather(const uint4 *log, const uint64_t *off, const uint32_t *
 /* SA[row] by the invPsi walk (bwt.c:311-329): one octet per row */
 __global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_t *SA, uint64_t sa0_index, const uint64_t *rows, uint64_t n, uint64_t *out) {
 	__shared__ uint64_t s_base[BWB_BASE_ROWS * 16];
-	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = ix.base[t >> 4][t & 15];
-	__syncthreads();
+	load_base<uint64_t>(s_base, ix);
 	const int lane = threadIdx.x & 63, ol = lane & 7;
 	const uint64_t noct = (uint64_t)gridDim.x * BWB_OCTS_PER_BLOCK;
 	for (uint64_t q = (uint64_t)blockIdx.x * BWB_OCTS_PER_BLOCK + (threadIdx.x >> 3); q < n; q += noct) {
 		uint64_t i = rows[q], j = 0;
 		while ((i & 31) != 0) { /* SA_INTERVAL = 32, bwt.h:16 */
 			if (i == sa0_index) { i = 0; j++; continue; } /* invPsi bwt.c:312-314 */
-			RankReq ra;
-			rank_issue(ix, i, ol, ra);
+			RankReq<uint64_t> ra;
+			rank_issue<uint64_t>(ix.buckets, ix.length - 1, i, ol, ra);
 			/* B(i), bwt.c:337-345: bit (i&31) of the planes held by lane 4 + ((i&127)>>5) */
 			const uint4 cq = ra.regular ? ra.q : ix.buckets[(i >> 7) * 8 + ol]; /* i == length-1 is not ranked via its bucket */
 			const int off = (int)(i & 127), srcl = (lane & ~7) + 4 + (off >> 5), bit = off & 31;
 			const uint32_t code_here = ((cq.x >> bit) & 1u) | (((cq.y >> bit) & 1u) << 1) | (((cq.z >> bit) & 1u) << 2) | (((cq.w >> bit) & 1u) << 3);
-			const uint32_t code = __shfl(code_here, srcl);
+			const uint32_t code = oct_bcast(code_here, srcl);
 			uint64_t v0, v1;
-			rank_finish(ra, s_base, ol, lane, false, v0, v1);
+			rank_finish<uint64_t, false>(ra, s_base, ol, lane, v0, v1);
 			/* C[c] + O(c,i): held by lane c>>1.  The sentinel row is stored as code 0 but is not a '$' (bwt.c:364) */
 			const uint64_t mine = (code & 1u) ? v1 : v0;
-			uint64_t nxt = oct_bcast64(mine, (lane & ~7) + (int)(code >> 1));
+			uint64_t nxt = oct_bcast(mine, (lane & ~7) + (int)(code >> 1));
 			if (code == 0 && ra.regular && sa0_index >= (i & ~127ull) && sa0_index <= i) nxt--;
 			i = nxt;
 			j++;

@@ -1,0 +1,743 @@
+/*
+ * bwb_lane.h - the alignment kernels, ONE READ PER LANE (gfx950).  Included by bwb_hip.hip.
+ *
+ * k_calc_d : calculate_d for the full read and for the seed (inexact_match.c:171-254, called at
+ *            inexact_match.c:140-143) -> one byte per position (num_diff clamped to 127, bit 7 =
+ *            "sa_intv_width equals the previous position's", the only way the width is ever used,
+ *            inexact_match.c:402-403,411-412).
+ * k_search : inexact_match (inexact_match.c:256-506) with exact_match_bounded (exact_match.c:66-119)
+ *            as a mode of the same per-lane loop: every loop iteration of every lane is one
+ *            rank visit pair (positions L-1 and U of one SA interval).
+ *
+ * Why one read per lane: a rank visit is 8 x global_load_dwordx4 of one 128-byte bucket per lane.
+ * Measured on MI355X (bwbble_amd/tools_exp/lane_bench.hip) these fully divergent 128-B gathers run
+ * at 50-54 G visits/s from the Infinity Cache and 40-43 G visits/s (5.2-5.5 TB/s) from HBM, and
+ * all control logic serves 64 reads per wave instruction instead of 8 (the octet version was
+ * VALU-bound at ~4 us per iteration).  Lanes pull reads from a global cursor (work stealing).
+ *
+ * Per-lane memory (global, private to the lane while it owns a read):
+ *   heap    : chains of 64-slot chunks from a shared pool (atomic bump allocation; chunks freed by
+ *             pops stay on the lane's private free list).  slot 0 = header {prev chunk}.
+ *   bstate  : [bucket][slot] u32 = chunk<<6 | fill; the bucket being popped is cached in registers.
+ *   lists   : two SA-interval lists (cur/next) with the open tail in registers.
+ *   hits    : the read's alignments (needed for the gapped-duplicate check, align.c:273-280).
+ * Per-read (not per-lane) data written by k_calc_d for k_search: for every read position i = 1..len the two
+ * bytes {D[i-1], D[i-2]} and {Dseed[si-1], Dseed[si-2]} (si = i - (len - seed_length)), plus the read's N count.
+ */
+#pragma once
+#include "bwb_device.h"
+#include "bwb_kernels.h"
+
+#define LANE_BLOCK 256
+/* lane-private LDS columns: explicit LDS address space, so they compile to ds_read/ds_write (a generic or volatile
+ * pointer here turns every access into a flat_* instruction with 64-bit addresses and full waits) */
+template <typename P> using Lds = __attribute__((address_space(3))) P *;
+#define CHUNK_SLOTS 64          /* slot 0 is the header: 63 entries per chunk */
+
+struct LaneScratch {
+	uint4 *pool;                /* chunk pool: chunk c at pool + c * CHUNK_SLOTS * (WIDE ? 2 : 1) */
+	unsigned int *pool_bump;    /* next never-used chunk */
+	uint32_t pool_cap;          /* chunks in the pool */
+	uint32_t *bstate;           /* [nb][nslots] */
+	void *lists;                /* [nslots][2*lcap] Intv<P> */
+	uint4 *alns;                /* [nslots][acap*2] */
+	uint2 *winfo;               /* [nslots][wstride] */
+	uint32_t nslots, lcap, acap, wstride;
+};
+
+/* ---- per-lane rank: C[j] + Occ(j,pos) for j = 1..15 -------------------------------------------- */
+template <typename P> struct LaneReq {
+	P pos;
+	bool regular;
+	int row;
+	uint4 d[8];
+};
+
+template <typename P>
+__device__ __forceinline__ void lane_issue(const uint4 *__restrict__ buckets, P last_row, P pos, LaneReq<P> &r) {
+	r.pos = pos;
+	const bool neg = (pos == (P)~(P)0), end = (pos == last_row);
+	r.regular = !(neg || end);
+	const P blk = pos >> 7;
+	r.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BWB_SB_SHIFT));
+	const uint4 *b = buckets + (size_t)(r.regular ? blk : 0) * 8;
+#pragma unroll
+	for (int k = 0; k < 8; k++) r.d[k] = b[k];
+}
+
+/* pop[j] = #j in the bucket's block at offsets [0, pos & 127], j = 1..15 */
+template <typename P>
+__device__ __forceinline__ void lane_pops(const LaneReq<P> &r, uint32_t pop[16]) {
+#pragma unroll
+	for (int c = 0; c < 16; c++) pop[c] = 0;
+	const int off = (int)(r.pos & 127);
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		const uint4 p = r.d[4 + w];
+		const int nv = off + 1 - 32 * w;
+		const uint32_t m = nv <= 0 ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+		const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
+		const uint32_t m2 = m & ~p.z, m2p = m & p.z;
+		const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
+#pragma unroll
+		for (int c = 1; c < 16; c++) pop[c] += __popc(a[c & 3] & b[c >> 2]);
+	}
+}
+/* C[j] + Occ(j, pos) from the bucket counts (slice s: {cnt[2s], cnt[2s+1], cnt[2s+8], cnt[2s+9]}) */
+template <typename P>
+__device__ __forceinline__ P lane_val(const LaneReq<P> &r, const P *brow, const uint32_t pop[16], int j) {
+	const uint32_t *cw = (const uint32_t *)&r.d[0];
+	const int s = (j & 7) >> 1, comp = (j & 1) + 2 * (j >> 3);
+	return brow[j] + (r.regular ? (P)(cw[4 * s + comp] + pop[j]) : (P)0);
+}
+
+#define KID_ROWS 20 /* rows 1..15: children with exact counts; rows 16..19: O_alphabet's values for codes 5, 9, 11, 13 */
+
+/* Children of the SA interval [iL, iU], staged in LDS (one column per lane):
+ *   rows 1..15 : child j = [C[j]+Occ(j,iL-1)+1, C[j]+Occ(j,iU)]                  (O(), bwt.c:348-372)
+ *   rows 16..19: the same for j = 5, 9, 11, 13 as O_alphabet computes them        (bwt.c:427-435,780)
+ * Returns ne_exact | ne_alphabet << 16: bit j = child j non-empty under either semantics. */
+template <typename P>
+__device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb, const P *s_base, Lds<P> kidL, Lds<P> kidU) {
+	uint32_t pop[16];
+	const P *cneg = s_base + BWB_ROW_NEG * 16;
+	{ /* L side: value + 1 (inc = 1, inexact_match.c:382) */
+		lane_pops<P>(ra, pop);
+		const P *brow = s_base + ra.row * 16;
+		const uint32_t first = (ra.d[4].x & 1u) | ((ra.d[4].y & 1u) << 1) | ((ra.d[4].z & 1u) << 2) | ((ra.d[4].w & 1u) << 3);
+#pragma unroll
+		for (int j = 1; j < 16; j++) kidL[j * LANE_BLOCK] = lane_val<P>(ra, brow, pop, j) + 1;
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const int j = q == 0 ? 5 : (q == 1 ? 9 : (q == 2 ? 11 : 13));
+			kidL[(16 + q) * LANE_BLOCK] = ra.regular ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0) + 1) : (P)(lane_val<P>(ra, brow, pop, j) + 1);
+		}
+	}
+	uint32_t ne = 0;
+	{
+		lane_pops<P>(rb, pop);
+		const P *brow = s_base + rb.row * 16;
+		const uint32_t first = (rb.d[4].x & 1u) | ((rb.d[4].y & 1u) << 1) | ((rb.d[4].z & 1u) << 2) | ((rb.d[4].w & 1u) << 3);
+#pragma unroll
+		for (int j = 1; j < 16; j++) {
+			const P U = lane_val<P>(rb, brow, pop, j);
+			kidU[j * LANE_BLOCK] = U;
+			const uint32_t bit = kidL[j * LANE_BLOCK] <= U ? 1u : 0u;
+			ne |= bit << j;
+			if (!(j == 5 || j == 9 || j == 11 || j == 13)) ne |= bit << (16 + j);
+		}
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const int j = q == 0 ? 5 : (q == 1 ? 9 : (q == 2 ? 11 : 13));
+			const P U = rb.regular ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : lane_val<P>(rb, brow, pop, j);
+			kidU[(16 + q) * LANE_BLOCK] = U;
+			ne |= (kidL[(16 + q) * LANE_BLOCK] <= U ? 1u : 0u) << (16 + j);
+		}
+	}
+	return ne;
+}
+/* LDS row of child j under O_alphabet semantics */
+__device__ __forceinline__ int alpha_row(int j) { return j == 5 ? 16 : (j == 9 ? 17 : (j == 11 ? 18 : (j == 13 ? 19 : j))); }
+
+/* ---- SA-interval list being built: add_sa_interval (align.c:93-110), tail in registers ------------ */
+template <typename P> struct ListW {
+	Intv<P> *buf;
+	int T;        /* intervals so far, including the open tail */
+	P tL, tU;
+};
+template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, P L, P U, int cap, bool &ovf) {
+	if (l.T != 0 && L == (P)(l.tU + 1)) { l.tU = U; return; }
+	if (l.T != 0) {
+		if (l.T - 1 >= cap) { ovf = true; return; }
+		l.buf[l.T - 1].L = l.tL; l.buf[l.T - 1].U = l.tU;
+	}
+	l.tL = L; l.tU = U; l.T++;
+}
+
+__device__ __forceinline__ uint32_t grab_read(const Batch &b) {
+	const uint32_t w = atomicAdd(b.counter, 1u); /* the compiler folds this into one atomic per wave */
+	if (w >= b.n_work) return NONE32;
+	return b.worklist ? b.worklist[w] : w;
+}
+
+/* ============================================================================================
+ * k_calc_d (one read per lane)
+ * ========================================================================================== */
+template <typename P>
+__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
+                                                        uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
+	extern __shared__ __align__(16) unsigned char smem[];
+	P *s_base = (P *)smem;
+	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
+	load_base<P>(s_base, ix);
+	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
+	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
+	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
+	const int cap = (int)sc.lcap;
+	const uint4 *__restrict__ buckets = ix.buckets;
+	const P last_row = (P)(ix.length - 1);
+
+	bool active = false, done = false;
+	uint32_t rid = 0;
+	int len = 0, phase = 0, plen = 0, r = 0, z = 0, s = 0, curT = 0, cursel = 0;
+	P cL = 0, cU = 0; /* tail (last interval) of the current list */
+	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
+	int32_t nm = 0, prev_nm = 0;
+	uint32_t prev_byte = 0, cntN = 0;
+	unsigned long long vis = 0;
+	uint32_t r_vis = 0;
+	const uint8_t *seq = b.reads;
+
+	for (;;) {
+		if (!active && !done) {
+			rid = grab_read(b);
+			if (rid == NONE32) done = true;
+			else {
+				len = b.lens[rid];
+				r_vis = 0;
+				seq = b.reads + (size_t)rid * b.stride;
+				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
+				cL = 0; cU = last_row; curT = 1;
+				nx.buf = lbase + cap; nx.T = 0;
+				active = len > 0;
+				if (!(kp.seed_length && len > kp.seed_length)) {
+					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads
+					 * whatever its thread's buffer holds.  We define that as the calloc'd zeros (num_diff 0, equal widths). */
+					uint16_t *Ws = (uint16_t *)(b.dbuf + (size_t)rid * b.dstride + b.dseed_off);
+					for (int i = 1; i <= len; i++) {
+						const int si = i - (len - kp.seed_length);
+						Ws[i] = (uint16_t)((si >= 1 ? 0x80u : 0u) | (si >= 2 ? 0x8000u : 0u));
+					}
+				}
+				if (!active) { b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = 0; b.status[rid] = ST_OK; }
+			}
+		}
+		if (__all(done)) break;
+		if (!active) continue;
+		const int c = seq[r];
+		bool ovf = false;
+		if (c > 3 && phase == 0) cntN++;
+		if (c <= 3) {
+			P iL, iU;
+			if (s == curT - 1) { iL = cL; iU = cU; }
+			else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
+			LaneReq<P> ra, rb;
+			lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
+			lane_issue<P>(buckets, last_row, iU, rb);
+			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
+			uint32_t ne = lane_children<P>(ra, rb, s_base, kidL, kidU);
+			ne &= member_mask(c);
+			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
+				const int j = __ffs((int)ne) - 1;
+				ne &= ne - 1;
+				const P L = kidL[j * LANE_BLOCK], U = kidU[j * LANE_BLOCK];
+				nm += (int32_t)(uint32_t)(U - L + 1);
+				list_add<P>(nx, L, U, cap, ovf);
+			}
+			s++;
+		}
+		if (ovf) { b.status[rid] = ST_SCRATCH_OVF; active = false; continue; }
+		if (c > 3 || s >= curT) {
+			/* position finished: swap lists (inexact_match.c:234-237) */
+			cursel ^= 1;
+			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
+			nx.buf = lbase + (cursel ^ 1) * cap; nx.T = 0; s = 0;
+			if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
+				cL = 0; cU = last_row; curT = 1; z++;
+				nm = (int32_t)(uint32_t)ix.length;
+			}
+			const int k = plen - 1 - r; /* D index */
+			{ /* D[k] is what an entry with e->i == k+1 reads as D[i-1] and one with e->i == k+2 as D[i-2] (:317,399-405) */
+				const uint32_t byte = (uint32_t)((z > 127 ? 127 : z) | ((k > 0 && nm == prev_nm) ? 0x80 : 0));
+				uint16_t *W = (uint16_t *)(b.dbuf + (size_t)rid * b.dstride + (phase ? b.dseed_off : 0));
+				const int i1 = phase ? k + 1 + (len - kp.seed_length) : k + 1; /* seed: si = k+1  ->  i = si + len - seed_length */
+				W[i1] = (uint16_t)(byte | (prev_byte << 8));
+				prev_byte = byte;
+			}
+			if (dbgD) {
+				int32_t *dst = phase ? dbgDs + ((size_t)rid * dbg_lds + k) * 2 : dbgD + ((size_t)rid * dbg_ld + k) * 2;
+				dst[0] = z; dst[1] = nm;
+			}
+			prev_nm = nm; nm = 0; r--;
+			if (r < 0) {
+				if (dbgD) { /* D[readLen] (inexact_match.c:249-250) */
+					int32_t *dst = phase ? dbgDs + ((size_t)rid * dbg_lds + plen) * 2 : dbgD + ((size_t)rid * dbg_ld + plen) * 2;
+					dst[0] = z + 1; dst[1] = 0;
+				}
+				if (phase == 0 && kp.seed_length && len > kp.seed_length) { /* inexact_match.c:141-143 */
+					phase = 1; plen = kp.seed_length; r = plen - 1; z = 0; prev_nm = 0; prev_byte = 0;
+					cL = 0; cU = last_row; curT = 1;
+				} else {
+					b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = (uint8_t)(cntN > 255 ? 255 : cntN);
+					b.status[rid] = ST_OK;
+					vis += r_vis;
+					active = false;
+				}
+			}
+		}
+	}
+	if (vis) atomicAdd(&stats[STAT_VIS_SINGLE], vis);
+}
+
+/* ============================================================================================
+ * k_search (one read per lane)
+ * ========================================================================================== */
+/* heap entry.  NARROW (P = u32 and max_gapo <= 1): 16 bytes {L, U, i|mm|go|ge, state|alen<<2|run<<10};
+ * WIDE: 32 bytes {L, U (64-bit each)} {i|mm|go|ge, state|alen<<8, runs lo, runs hi}.
+ * runs: one 16-bit word per gap open: start | len<<8 | isD<<15, 0xFFFF = unused. */
+template <typename P> struct LEntry {
+	P L, U;
+	uint32_t f;        /* i | mm<<8 | go<<16 | ge<<24 */
+	uint32_t sa;       /* state | alen<<2 */
+	uint32_t runsLo, runsHi;
+};
+
+/* Score-bucketed LIFO heap (inexact_match.h:17-34, inexact_match.c:510-610): every bucket is a chain of 64-slot
+ * chunks.  Chunk header (slot 0): .x = next chunk of the lane's free list, .y = state word of the bucket before this
+ * chunk was started (so a chunk may be left partially filled), .z = next chunk in the lane's "owned" chain.
+ * A bucket state word is chunk<<6 | fill (fill = index of the top entry, 1..63), NONE32 when empty. */
+template <typename P, bool WIDE> struct LHeap {
+	uint4 *pool;
+	unsigned int *pool_bump;
+	uint32_t pool_cap;
+	uint32_t *bstate;      /* this lane's column: bstate[s * nslots] */
+	uint32_t nslots;
+	uint32_t fhead;        /* chunks emptied by pops during this read */
+	uint32_t ohead, otail, ocur; /* every chunk this lane ever took from the pool, in allocation order; a new read
+	                                rewinds ocur, so resetting the heap costs nothing */
+	uint64_t neLo, neHi;   /* non-empty buckets */
+	int cb;                /* bucket whose state is cached in registers = score of the entry last popped */
+	uint32_t cst;
+	int num_entries;
+	LEntry<P> top;         /* register mirror of the entry on top of bucket cb's memory stack */
+	bool top_valid;
+
+	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
+	__device__ __forceinline__ void reset() { fhead = NONE32; ocur = ohead; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
+	__device__ __forceinline__ void mark(int s) { if (s < 64) neLo |= 1ull << s; else neHi |= 1ull << (s - 64); }
+	__device__ __forceinline__ void unmark(int s) { if (s < 64) neLo &= ~(1ull << s); else neHi &= ~(1ull << (s - 64)); }
+	__device__ __forceinline__ int best(int nb) const {
+		return neLo ? __ffsll((long long)neLo) - 1 : (neHi ? 64 + __ffsll((long long)neHi) - 1 : nb);
+	}
+	__device__ __forceinline__ void switch_cache(int s) {
+		if (s == cb) return;
+		bstate[(size_t)cb * nslots] = cst;
+		cb = s; cst = bstate[(size_t)s * nslots];
+		top_valid = false;
+	}
+	__device__ __forceinline__ uint32_t alloc(bool &ovf) {
+		if (fhead != NONE32) { const uint32_t c = fhead; fhead = chunk_ptr(c)[0].x; return c; }
+		if (ocur != NONE32) { const uint32_t c = ocur; ocur = chunk_ptr(c)[0].z; return c; }
+		const uint32_t c = atomicAdd(pool_bump, 1u);
+		if (c >= pool_cap) { ovf = true; return 0; }
+		chunk_ptr(c)[0].z = NONE32;
+		if (otail != NONE32) chunk_ptr(otail)[0].z = c; else ohead = c;
+		otail = c;
+		return c;
+	}
+	/* makes room for k (<= 63) more entries on a bucket whose state is st; returns the state to push from */
+	__device__ __forceinline__ uint32_t reserve(uint32_t st, int k, bool &ovf) {
+		if (k > 0 && (st == NONE32 || (int)(st & 63u) + k > CHUNK_SLOTS - 1)) {
+			const uint32_t c = alloc(ovf);
+			if (ovf) return st;
+			chunk_ptr(c)[0].y = st;
+			return c << 6;
+		}
+		return st;
+	}
+	__device__ __forceinline__ void store_entry(uint32_t st, const LEntry<P> &e) const {
+		uint4 *p = chunk_ptr(st >> 6);
+		const uint32_t fill = st & 63u;
+		if (WIDE) {
+			p[fill * 2] = make_uint4((uint32_t)e.L, (uint32_t)((uint64_t)e.L >> 32), (uint32_t)e.U, (uint32_t)((uint64_t)e.U >> 32));
+			p[fill * 2 + 1] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
+		} else p[fill] = make_uint4((uint32_t)e.L, (uint32_t)e.U, e.f, e.sa | (e.runsLo << 10));
+	}
+	__device__ __forceinline__ void load_entry(uint32_t st, LEntry<P> &e) const {
+		const uint4 *p = chunk_ptr(st >> 6);
+		const uint32_t fill = st & 63u;
+		if (WIDE) {
+			const uint4 w0 = p[fill * 2], w1 = p[fill * 2 + 1];
+			e.L = (P)(((uint64_t)w0.y << 32) | w0.x); e.U = (P)(((uint64_t)w0.w << 32) | w0.z);
+			e.f = w1.x; e.sa = w1.y; e.runsLo = w1.z; e.runsHi = w1.w;
+		} else {
+			const uint4 w = p[fill];
+			e.L = (P)w.x; e.U = (P)w.y; e.f = w.z; e.sa = w.w & 0x3FFu;
+			e.runsLo = 0xFFFF0000u | (w.w >> 10); e.runsHi = 0xFFFFFFFFu;
+		}
+	}
+	/* pops the top entry of the cached bucket cb (the best non-empty one) */
+	__device__ __forceinline__ void pop(LEntry<P> &e) {
+		if (top_valid) e = top; else load_entry(cst, e);
+		if ((cst & 63u) == 1u) {
+			uint4 *p = chunk_ptr(cst >> 6);
+			const uint32_t pv = p[0].y;
+			p[0].x = fhead; fhead = cst >> 6; /* chunk goes to the private free list */
+			cst = pv;
+			if (pv == NONE32) unmark(cb);
+			top_valid = false;
+		} else {
+			cst--;
+			load_entry(cst, top); /* prefetch the new top: needed at the earliest by the next pop */
+			top_valid = true;
+		}
+		num_entries--;
+	}
+};
+
+#define LMODE_POP 0
+#define LMODE_EXACT 1
+#ifdef BWB_STAMPS
+#define STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+template <typename P, bool WIDE>
+__global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b, KParams kp, LaneScratch sc, OutBuf out, unsigned long long *stats) {
+	extern __shared__ __align__(16) unsigned char smem[];
+	P *s_base = (P *)smem;
+	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
+	load_base<P>(s_base, ix);
+	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
+	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
+	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
+	uint4 *myalns = sc.alns + (size_t)slot * sc.acap * 2;
+	const int lcap = (int)sc.lcap;
+	const int nb = kp.num_buckets;
+	const uint4 *__restrict__ buckets = ix.buckets;
+	const P last_row = (P)(ix.length - 1);
+
+	LHeap<P, WIDE> h;
+	h.pool = sc.pool; h.pool_bump = sc.pool_bump; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
+	h.ohead = h.otail = h.ocur = NONE32;
+	h.reset();
+	for (int k = 0; k < nb; k++) h.bstate[(size_t)k * h.nslots] = NONE32;
+
+	bool active = false, done = false;
+	uint32_t rid = 0;
+	int len = 0, mode = LMODE_POP;
+	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
+	int r = 0, s = 0, curT = 0, cursel = 0;                 /* exact-tail state */
+	P cL = 0, cU = 0;
+	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
+	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
+	int e_score = 0;
+	/* "hot" entry: the last child pushed on the bucket being popped stays in registers; it is exactly the entry the
+	 * next heap_pop returns (LIFO inside the best bucket, inexact_match.c:594-597), so chains of matches never go
+	 * through memory.  It is counted in num_entries and in the non-empty bitmap like any other entry. */
+	LEntry<P> hot = e;
+	bool hot_valid = false;
+	const uint16_t *Wd = (const uint16_t *)b.dbuf, *Ws = Wd;
+	const uint8_t *seq = b.reads;
+	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
+	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed only when the read completes */
+	unsigned long long n_iter = 0;
+	uint32_t r_iter = 0;
+#ifdef BWB_STAMPS
+	unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
+#endif
+
+	for (;;) {
+		STAMP(7);
+		if (!active && !done) {
+			rid = grab_read(b);
+			if (rid == NONE32) done = true;
+			else {
+				r_vis_s = r_vis_a = r_pop = r_push = 0; r_iter = 0;
+				len = b.lens[rid];
+				seq = b.reads + (size_t)rid * b.stride;
+				Wd = (const uint16_t *)(b.dbuf + (size_t)rid * b.dstride);
+				Ws = (const uint16_t *)(b.dbuf + (size_t)rid * b.dstride + b.dseed_off);
+				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
+				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
+				hot_valid = false;
+				n_alns = 0; mode = LMODE_POP; active = true;
+				if (!(cntN > kp.max_diff || len == 0)) { /* inexact_match.c:260-266 */
+					/* heap_push(root) inexact_match.c:281 */
+					hot.L = 0; hot.U = last_row; hot.f = (uint32_t)len; hot.sa = 0; hot.runsLo = hot.runsHi = ~0u;
+					hot_valid = true; h.neLo = 1; h.num_entries = 1;
+					r_push++;
+				}
+				best_score = kp.num_buckets; /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
+				max_diff = kp.max_diff; num_best = 0;
+			}
+		}
+		if (__all(done)) break;
+		if (!active) continue;
+
+		bool finish = false, ovf = false, from_pop = false, need_rank = false;
+		P iL = 0, iU = 0;
+		int widx = 0;
+		n_iter++; r_iter++;
+
+		/* add_alignment (align.c:271-298) into the lane's private hit list */
+		auto add_aln = [&](P L, P U, int score, int alen) {
+			const int e_go = (e.f >> 16) & 255;
+			if (e_go) {
+				for (int j = 0; j < n_alns; j++) {
+					const uint4 a = myalns[j * 2];
+					if (a.x == (uint32_t)L && a.y == (uint32_t)((uint64_t)L >> 32) && a.z == (uint32_t)U && a.w == (uint32_t)((uint64_t)U >> 32)) return;
+				}
+			}
+			if (n_alns >= (int)sc.acap) { ovf = true; return; }
+			myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
+			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 255) | (e.f & 0xFFFFFF00u), (uint32_t)(alen & 255), e.runsLo, e.runsHi);
+			n_alns++;
+		};
+
+		STAMP(0);
+		/* ---- A: pick the SA interval of this iteration ---- */
+		if (mode == LMODE_POP) {
+			if (h.num_entries == 0 || h.num_entries > kp.max_entries) finish = true; /* :293,299 */
+			else {
+				/* heap_pop :594-610 */
+				if (hot_valid) {
+					e = hot; hot_valid = false; h.num_entries--; /* e_score stays: the hot entry lives on the bucket just popped */
+					if (h.cst == NONE32) h.unmark(h.cb);
+				} else {
+					const int bk = h.best(nb);
+					h.switch_cache(bk);
+					h.pop(e);
+				}
+				e_score = h.cb;
+				r_pop++;
+				if (e_score > best_score + kp.mm_score) finish = true; /* :309 */
+				else {
+					from_pop = true;
+					widx = (int)(e.f & 255u);
+					if (widx > 0) { need_rank = true; iL = e.L; iU = e.U; }
+				}
+			}
+		} else { /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
+			widx = r + 1;
+			if (s == curT - 1) { iL = cL; iU = cU; }
+			else { const Intv<P> v = (lbase + cursel * lcap)[s]; iL = v.L; iU = v.U; }
+			need_rank = true;
+		}
+
+		STAMP(1);
+		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
+		uint32_t wd = 0, ws = 0, ne = 0;
+		int cr = 4, nvis = 0;
+		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504) */
+		const int e_state = (int)(e.sa & 3u);
+		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
+		uint32_t stX = NONE32, stG = NONE32;
+		if (need_rank) {
+			LaneReq<P> ra, rb;
+			lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
+			lane_issue<P>(buckets, last_row, iU, rb);
+			wd = Wd[widx]; ws = Ws[widx];
+			const int cf = seq[len - widx]; /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
+			cr = cf > 3 ? 4 : 3 - cf;
+			if (from_pop) { /* (clamped: an entry near the top score is never expanded, but the prefetch is unconditional) */
+				stX = h.bstate[(size_t)(scX < nb ? scX : nb - 1) * h.nslots];
+				stG = h.bstate[(size_t)(scG < nb ? scG : nb - 1) * h.nslots];
+			}
+			nvis = (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
+			STAMP(2);
+			ne = lane_children<P>(ra, rb, s_base, kidL, kidU);
+		}
+		STAMP(3);
+
+		/* ---- C: act on it ---- */
+		bool exact_step = (mode == LMODE_EXACT);
+		if (from_pop) {
+			const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
+			const int e_alen = (int)((e.sa >> 2) & 255u);
+			const int diff_left = max_diff - e_mm - e_go - e_ge;
+			const int diff_left_seed = kp.max_diff_seed - e_mm - e_go - e_ge;
+			const int seed_index = e_i - (len - kp.seed_length);
+			bool pruned = diff_left < 0;                                                                  /* :313 */
+			if (!pruned && e_i > 0 && diff_left < (int)(wd & 127u)) pruned = true;                        /* :317 */
+			if (!pruned && seed_index > 0 && diff_left_seed < (int)(ws & 127u)) pruned = true;            /* :326 */
+			if (!pruned) {
+				if (e_i == 0) { /* hit :331-344 */
+					if (n_alns == 0) {
+						best_score = e_score;
+						const int bd = e_mm + e_go + e_ge;
+						max_diff = (bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1;
+					}
+					if (e_score == best_score) { num_best += (int)(uint32_t)(e.U - e.L + 1); add_aln(e.L, e.U, e_score, e_alen); }
+					else if (num_best > kp.max_best) finish = true;
+					else add_aln(e.L, e.U, e_score, e_alen);
+				} else if (diff_left == 0) { /* exact tail :345-375: its first step uses the children just computed */
+					cL = e.L; cU = e.U; curT = 1; cursel = 0; s = 0; r = e_i - 1;
+					nx.buf = lbase + lcap; nx.T = 0;
+					mode = LMODE_EXACT;
+					exact_step = true;
+				} else {
+					/* ---- expansion :377-504 ---- */
+					r_vis_a += nvis;
+					const uint32_t nea = ne >> 16; /* non-empty children under O_alphabet semantics */
+					bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
+					if (e_i - 1 > 0) {
+						const int d1 = wd & 255u, d2 = (wd >> 8) & 255u;
+						if ((diff_left - 1) < (d2 & 127)) allow_diff = false;
+						else if ((d1 & 127) == diff_left - 1 && (d2 & 127) == diff_left - 1 && (d1 & 128)) allow_mm = false;
+					}
+					if (seed_index - 1 > 0) {
+						const int d1 = ws & 255u, d2 = (ws >> 8) & 255u;
+						if ((diff_left_seed - 1) < (d2 & 127)) allow_diff = false;
+						else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
+					}
+					const int tmp = e_go + e_ge;
+					if ((e_i - 1 < kp.no_indel_length + tmp) || ((len - (e_i - 1)) < kp.no_indel_length + tmp)) allow_indels = false;
+					if (e_go >= kp.max_gapo && e_ge >= kp.max_gape) allow_indels = false;
+					if (e_go >= kp.max_gapo) allow_open = false;
+					if (e_ge >= kp.max_gape) allow_extend = false;
+					const bool gap_open = e_state == STATE_M;
+					const int sc0 = e_score;
+					const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
+					const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
+					const bool mm_ok = allow_diff && allow_mm;
+					const uint32_t mem = cr > 3 ? 0u : member_mask(cr);
+					/* push sequence (:434-504): bit 0 insertion, bits 1..15 deletions j, bits 16+j match/mismatch j */
+					const uint32_t gapm = (ins_ok ? 1u : 0u) | (del_ok ? nea : 0u);
+					const uint32_t mgrp = mm_ok ? nea : (nea & mem);
+					const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
+					uint32_t seqm = gapm | (mgrp << 16);
+					r_push += __popc(seqm);
+					/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
+					const int tX = scX == sc0 ? 0 : 1, tG = scG == sc0 ? 0 : (scG == scX ? tX : 2);
+					const uint32_t m0 = (matchm << 16) | (tX == 0 ? mism << 16 : 0u) | (tG == 0 ? gapm : 0u);
+					const int hotbit = m0 ? 31 - __clz((int)m0) : -1;     /* the last entry landing on sc0 stays in registers */
+					const int k0 = __popc(m0) - (m0 ? 1 : 0);
+					const int k1 = (tX == 1 ? __popc(mism) : 0) + (tG == 1 ? __popc(gapm) : 0);
+					const int k2 = tG == 2 ? __popc(gapm) : 0;
+					uint32_t st0 = h.reserve(h.cst, k0, ovf);
+					uint32_t st1 = h.reserve(stX, k1, ovf);
+					uint32_t st2 = h.reserve(stG, k2, ovf);
+					if (!ovf) {
+						/* child entry templates */
+						const uint32_t alen1 = (uint32_t)((e_alen + 1) & 255);
+						const uint32_t f_base = ((uint32_t)e_go << 16) | ((uint32_t)e_ge << 24);
+						const uint32_t f_match = (uint32_t)((e_i - 1) & 255) | ((uint32_t)e_mm << 8) | f_base;
+						const uint32_t f_mis = (uint32_t)((e_i - 1) & 255) | ((uint32_t)((e_mm + 1) & 255) << 8) | f_base;
+						const uint32_t f_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
+						const uint64_t eruns = ((uint64_t)e.runsHi << 32) | e.runsLo;
+						uint64_t gruns_i, gruns_d; /* new run on open (start = aln_length, len 1); len+1 on extend */
+						if (gap_open) {
+							const int sh = 16 * (e_go & 3);
+							const uint64_t cleared = eruns & ~(0xFFFFull << sh);
+							gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
+							gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
+						} else gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
+						LEntry<P> ch;
+						while (seqm) {
+							const int q = __ffs((int)seqm) - 1;
+							seqm &= seqm - 1;
+							const bool isgap = q < 16, is_ins = q == 0;
+							const int j = q & 15;
+							const bool is_mis = !isgap && !((mem >> j) & 1u);
+							const int row = alpha_row(j);
+							ch.L = is_ins ? e.L : kidL[row * LANE_BLOCK];
+							ch.U = is_ins ? e.U : kidU[row * LANE_BLOCK];
+							ch.f = isgap ? (f_gap | (uint32_t)((is_ins ? e_i - 1 : e_i) & 255)) : (is_mis ? f_mis : f_match);
+							ch.sa = (isgap ? (is_ins ? STATE_I : STATE_D) : STATE_M) | (alen1 << 2);
+							const uint64_t rr = isgap ? (is_ins ? gruns_i : gruns_d) : eruns;
+							ch.runsLo = (uint32_t)rr; ch.runsHi = (uint32_t)(rr >> 32);
+							const int t = isgap ? tG : (is_mis ? tX : 0);
+							if (q == hotbit) { hot = ch; hot_valid = true; }
+							else {
+								uint32_t st = t == 0 ? st0 : (t == 1 ? st1 : st2);
+								st++;
+								h.store_entry(st, ch);
+								if (t == 0) { st0 = st; h.top = ch; } else if (t == 1) st1 = st; else st2 = st;
+							}
+						}
+						h.num_entries += __popc(gapm) + __popc(mgrp);
+						if (m0) h.mark(sc0);
+						if (k0 > 0) { h.cst = st0; h.top_valid = true; }
+						if (k1 > 0) { h.bstate[(size_t)(tX == 1 ? scX : scG) * h.nslots] = st1; h.mark(tX == 1 ? scX : scG); }
+						if (k2 > 0) { h.bstate[(size_t)scG * h.nslots] = st2; h.mark(scG); }
+					}
+				}
+			}
+		}
+
+		STAMP(4);
+		if (exact_step && need_rank) {
+			bool exact_done = false;
+			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
+			else {
+				r_vis_s += nvis;
+				uint32_t nm = ne & 0xFFFFu & member_mask(cr);
+				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
+					const int j = __ffs((int)nm) - 1;
+					nm &= nm - 1;
+					list_add<P>(nx, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], lcap, ovf);
+				}
+				s++;
+				if (!ovf && s >= curT) {
+					cursel ^= 1; curT = nx.T; cL = nx.tL; cU = nx.tU;
+					nx.buf = lbase + (cursel ^ 1) * lcap; nx.T = 0; s = 0;
+					if (curT == 0) exact_done = true; /* :114 */
+					else { r--; if (r < 0) exact_done = true; }
+				}
+			}
+			if (exact_done && !ovf) {
+				mode = LMODE_POP;
+				if (curT != 0) { /* matches found :347-371 */
+					const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
+					if (n_alns == 0) {
+						best_score = e_score;
+						const int bd = e_mm + e_go + e_ge;
+						max_diff = (bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1;
+					}
+					bool brk = false;
+					if (e_score == best_score) {
+						for (int k = 0; k < curT; k++) {
+							P L, U;
+							if (k == curT - 1) { L = cL; U = cU; }
+							else { const Intv<P> v = (lbase + cursel * lcap)[k]; L = v.L; U = v.U; }
+							num_best += (int)(uint32_t)(U - L + 1);
+						}
+					} else if (num_best > kp.max_best) brk = true;
+					if (brk) finish = true;
+					else {
+						const int alen2 = ((int)((e.sa >> 2) & 255u) + e_i) & 255; /* :365 */
+						for (int k = 0; k < curT && !ovf; k++) {
+							P L, U;
+							if (k == curT - 1) { L = cL; U = cU; }
+							else { const Intv<P> v = (lbase + cursel * lcap)[k]; L = v.L; U = v.U; }
+							add_aln(L, U, e_score, alen2);
+						}
+					}
+				}
+			}
+		}
+
+		STAMP(5);
+		if (ovf) finish = true;
+		if (finish) {
+			unsigned long long off = 0;
+			bool outovf = false;
+			if (!ovf && n_alns > 0) {
+				off = atomicAdd(out.count, (unsigned long long)n_alns);
+				if (off + (unsigned long long)n_alns > out.cap) outovf = true;
+				else for (int t = 0; t < n_alns * 2; t++) out.alns[off * 2 + t] = myalns[t];
+			}
+			out.off[rid] = off;
+			out.n[rid] = (ovf || outovf) ? 0u : (uint32_t)n_alns;
+			b.status[rid] = ovf ? ST_SCRATCH_OVF : (outovf ? ST_OUT_OVF : ST_OK);
+			if (b.dbg_iters) b.dbg_iters[rid] = r_iter;
+			if (!ovf && !outovf) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
+			/* leave every bucket state empty for the next read */
+			h.bstate[(size_t)h.cb * h.nslots] = NONE32;
+			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[(size_t)k * h.nslots] = NONE32; h.unmark(k); }
+			active = false;
+		}
+	}
+	if (vis_s) atomicAdd(&stats[STAT_VIS_SINGLE], vis_s);
+	if (vis_a) atomicAdd(&stats[STAT_VIS_ALPHA], vis_a);
+	if (n_pop) atomicAdd(&stats[STAT_POPS], n_pop);
+	if (n_push) atomicAdd(&stats[STAT_PUSHES], n_push);
+	if (n_aln_tot) atomicAdd(&stats[STAT_ALNS], n_aln_tot);
+	atomicAdd(&stats[STAT_N], n_iter);        /* debug: total loop iterations */
+	atomicMax(&stats[STAT_N + 1], n_iter);    /* debug: longest lane */
+#ifdef BWB_STAMPS
+	if (n_iter) for (int k = 0; k < 8; k++) atomicAdd(&stats[8 + k], seg[k]);
+#endif
+}
