@@ -37,22 +37,13 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BWB_BENCH_DIR", "/tmp/bwb_bench"))
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    dist = None
     import torch  # plumbing only (synchronize, barrier, max-over-ranks); imported first so that one HIP runtime is shared
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import numpy as np
     import bwbble_amd as bw
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    from bwbble_amd import dist as bdist
+    grp = bdist.Group()  # one process per GPU; backend nccl (= RCCL) when launched by torch.distributed.run
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    barrier = grp.barrier
 
     # ---- workload: synthetic genome + index (built once, by rank 0, with the product's own indexer) ----------
     n_fwd = int(a.genome_mb * 1e6)
@@ -68,7 +59,7 @@ def main():
     fq = os.path.join(a.workdir, f"reads_{n_fwd}_{a.reads}_{a.read_len}_r{rank}.fq")
     if not os.path.exists(fq):
         subprocess.run([bw.SYNTH_BIN, "reads", fa, fq, str(a.reads), str(a.read_len), str(1000 + rank), "1.0", "0.1", "0.0"], check=True)
-    seqs, lens = bw.encode_reads(bw.read_fastq(fq))
+    seqs, lens = bw.load_fastq_codes(fq)
     flags = ["-n", str(a.ndiff)]
     p = bw.params(flags)
     bwt = bw.BwtFile(fa + ".bwt")
@@ -89,17 +80,13 @@ def main():
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt, kern_ms, visits], dtype=torch.float64, device=f"cuda:{local_rank}")
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, kern_ms, visits = float(tmax[0]), float(tmax[1]), float(tsum[2]) / world
+    dt, kern_ms, visits_all = grp.reduce_step(dt, kern_ms, visits)  # MAX time over ranks, SUM of visits
+    visits = visits_all / world
     st = ctx.stats()
     off, alns = ctx.result()
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        grp.close()
         return
     total_reads = a.reads * world * a.steps
     value = total_reads / dt
@@ -124,9 +111,19 @@ def main():
     # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only) --------------------------------
     if world == 1:
         out["cpu_baseline"] = cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw)
+        if a.ndiff != 0:
+            # the reference's literal CLI default is -n 0 (align.c:26): same reads, same index, reported next to the main line
+            ctx.upload(bw.params(["-n", "0"]), seqs, lens)
+            ctx.run()
+            t1 = time.perf_counter(); ctx.run(); d0 = time.perf_counter() - t1
+            s0 = ctx.stats()
+            v0 = s0.visits_single + s0.visits_alphabet
+            ach0 = v0 * ALG_BYTES_PER_VISIT / ((s0.ms_calc_d + s0.ms_search) * 1e-3) / 1e9
+            out["also"] = {"n0": {"workload": "same batch, align -n 0 (CLI default)", "value": round(a.reads / d0, 1), "unit": "reads/s",
+                                  "ms_per_step": round(d0 * 1e3, 3), "roofline_achieved_GBs": round(ach0, 1),
+                                  "roofline_frac": round(ach0 / HBM_PEAK_GBS, 4), "visits_per_step": int(v0)}}
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 def cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw):

@@ -230,6 +230,29 @@ def encode_reads(ascii_reads):
     return seqs, lens
 
 
+def load_fastq_codes(path, max_reads=0):
+    """FASTQ -> (codes (n, stride) uint8, lens uint16) without a Python loop per read (same encoding as encode_reads)."""
+    data = np.fromfile(path, dtype=np.uint8)
+    nl = np.flatnonzero(data == 10)
+    if len(data) and data[-1] != 10:
+        nl = np.append(nl, len(data))
+    starts = np.concatenate(([0], nl[:-1] + 1))
+    n = len(nl) // 4
+    if max_reads:
+        n = min(n, max_reads)
+    s0, e0 = starts[1:4 * n:4], nl[1:4 * n:4]
+    lens = (e0 - s0).astype(np.uint16)
+    stride = int(lens.max()) if n else 1
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in (("A", 0), ("G", 1), ("C", 2), ("T", 3)):
+        lut[ord(ch)] = v
+        lut[ord(ch.lower())] = v
+    idx = s0[:, None] + np.arange(stride)[None, :]
+    valid = np.arange(stride)[None, :] < lens[:, None]
+    seqs = np.where(valid, lut[data[np.minimum(idx, len(data) - 1)]], 4).astype(np.uint8)
+    return seqs, lens
+
+
 def read_fastq(path, max_reads=0):
     """Sequence lines of a 4-line FASTQ (the subset of fastq2reads, io.c:410-515, that align needs)."""
     out = []

@@ -3,10 +3,10 @@
  *
  * Host orchestration of one batch (replaces the per-batch body of align_reads_inexact_parallel,
  * mg-aligner/inexact_match.c:103-165):
- *   1. k_calc_d over all reads (work-stealing octets);
- *   2. k_search over all reads with the class-0 per-octet scratch; reads whose heap / interval list /
- *      hit list did not fit are re-run -- still on the GPU -- in class 1, then class 2 (class 2 holds
- *      max_entries heap entries, the reference's own bound, inexact_match.c:299);
+ *   1. kl_calc_d over all reads (one read per lane, lanes pull reads from a global cursor);
+ *   2. kl_search over all reads with the class-0 per-lane scratch and the shared heap chunk pool; reads whose
+ *      interval list / hit list did not fit, or that found the pool empty, are re-run -- still on the GPU --
+ *      in class 1, then class 2 (fewer lanes, larger lists, a fresh pool);
  *   3. hits gathered into read order.
  * There is no CPU fallback anywhere in this file.
  */
@@ -196,7 +196,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	ScratchClass &s = c->cls[k];
 	uint32_t blocks, lcap, acap;
 	if (k == 0) {
-		int bpc = 2;
+		int bpc = 2; /* 8 waves per CU: measured best (1 block: 2129 ms, 2 blocks: 1645 ms on the chr21-scale -n 3 batch) */
 		if (getenv("BWB_BLOCKS_PER_CU")) bpc = atoi(getenv("BWB_BLOCKS_PER_CU"));
 		if (bpc < 1) bpc = 1;
 		blocks = (uint32_t)(c->num_cu * bpc); lcap = 1024; acap = 64;
@@ -599,5 +599,14 @@ extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, ui
 extern "C" int bwb_hip_debug_iters(bwb_hip_ctx *c, uint32_t *out) {
 	if (!c || !c->d_dbg_iters) return fail(BWB_E_STATE, "debug iteration counts are off (set BWB_DEBUG_ITERS)");
 	HIPCHK(hipMemcpy(out, c->d_dbg_iters, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
+	return BWB_OK;
+}
+
+/* developer aid: k_calc_d visits per read of the last batch_run */
+extern "C" int bwb_hip_debug_calcd_work(bwb_hip_ctx *c, uint32_t *out) {
+	if (!c || !c->uploaded) return fail(BWB_E_STATE, "no batch");
+	std::vector<uint8_t> h((size_t)c->n_reads * c->dstride);
+	HIPCHK(hipMemcpy(h.data(), c->d_dbuf, h.size(), hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < c->n_reads; i++) memcpy(&out[i], &h[(size_t)i * c->dstride + c->dstride - 8], 4);
 	return BWB_OK;
 }

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 					cL = 0; cU = last_row; curT = 1;
 				} else {
 					b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = (uint8_t)(cntN > 255 ? 255 : cntN);
+					*(uint32_t *)(b.dbuf + (size_t)rid * b.dstride + b.dstride - 8) = r_vis; /* work done for this read: a cheap predictor of search cost */
 					b.status[rid] = ST_OK;
 					vis += r_vis;
 					active = false;
@@ -387,6 +388,9 @@ template <typename P, bool WIDE> struct LHeap {
 
 #define LMODE_POP 0
 #define LMODE_EXACT 1
+#define STATE_M 0 /* align.h:16-18 */
+#define STATE_I 1
+#define STATE_D 2
 #ifdef BWB_STAMPS
 #define STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
 #else
