@@ -89,7 +89,7 @@ __device__ __forceinline__ void rank_issue(const uint4 *__restrict__ buckets, P 
  * DevIndex::base (as P).
  */
 template <typename P, bool QUIRK>
-__device__ __forceinline__ void rank_finish(const RankReq<P> &r, const P *s_base, int ol, int lane, P &v0, P &v1) {
+__device__ __forceinline__ void rank_finish(const RankReq<P> &r, const P *s_base, int ol, int lane, P &v0, P &v1, uint32_t *first_out = nullptr) {
 	const uint4 q = r.q;
 	/* position mask of this lane's 32-character sub-block (lanes 0..3 hold counts: empty mask) */
 	const int off = (int)(r.pos & 127);
@@ -117,6 +117,8 @@ __device__ __forceinline__ void rank_finish(const RankReq<P> &r, const P *s_base
 	const P *brow = s_base + r.row * 16 + 2 * ol;
 	v0 = brow[0] + c0 + pop0;
 	v1 = brow[1] + c1 + pop1;
+	if (first_out) /* first character of the block: bit 0 of the four planes held by lane 4 */
+		*first_out = oct_bcast((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);
 	if (QUIRK) {
 		/* first character of the block (bwt.c:780): bit 0 of the four planes held by lane 4 */
 		const uint32_t first = oct_bcast((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);

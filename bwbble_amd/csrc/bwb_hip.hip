@@ -296,6 +296,7 @@ static Batch make_batch(bwb_hip_ctx *c, const uint32_t *worklist, uint32_t n_wor
 	b.dbuf = c->d_dbuf; b.dstride = c->dstride; b.dseed_off = c->dseed_off;
 	b.worklist = worklist; b.n_work = n_work; b.counter = c->d_counter; b.status = c->d_status;
 	b.dbg_iters = c->d_dbg_iters;
+	b.iter_budget = 0; b.lane_stride = 1;
 	return b;
 }
 
@@ -352,14 +353,16 @@ static int run_calc_d(bwb_hip_ctx *c, int32_t *dbgD, int32_t *dbgDs) {
 	return BWB_OK;
 }
 
-static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work) {
+static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work, uint32_t iter_budget = 0, uint32_t lane_stride = 1) {
 	ScratchClass &s = c->cls[k];
 	Batch b = make_batch(c, wl, n_work);
+	b.iter_budget = iter_budget; b.lane_stride = lane_stride;
 	OutBuf ob{ c->d_log, c->d_count, c->log_cap, c->d_off, c->d_n };
 	const size_t lds = lane_lds(c);
 	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
 	HIPCHK(hipMemsetAsync(c->d_pool_bump, 0, 4, c->stream)); /* every launch starts with an empty chunk pool */
-	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
+	const uint32_t per_block = LANE_BLOCK / lane_stride;
+	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + per_block - 1) / per_block));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	if (c->pos32 && !c->wide)
 		hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
@@ -376,7 +379,7 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	if (getenv("BWB_DEBUG")) {
 		unsigned int used = 0;
 		hipMemcpy(&used, c->d_pool_bump, 4, hipMemcpyDeviceToHost);
-		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, lds %zu B, %.3f ms, pool chunks used %u of %u\n", k, n_work, grid, lds, ms, used, s.sc.pool_cap);
+		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, budget %u, lane stride %u, %.3f ms, pool chunks used %u of %u\n", k, n_work, grid, iter_budget, lane_stride, ms, used, s.sc.pool_cap);
 	}
 	return BWB_OK;
 }
@@ -418,11 +421,24 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	HIPCHK(hipEventRecord(t0, c->stream));
 	int rc = run_calc_d(c, nullptr, nullptr);
 	if (rc) return rc;
-	rc = launch_search(c, 0, nullptr, c->n_reads);
-	if (rc) return rc;
-	rc = rerun_out_overflow(c, 0);
+	/* phase 1: every read, with an iteration budget; phase 2: the reads that exceeded it (the heavy tail),
+	 * restarted together, one per octet, so that each runs the low-latency cooperative path from the start */
+	uint32_t budget = 0; /* off by default: measured slower than one launch (1534 + 770 ms vs 2105 ms, chr21-scale -n 3, 1 M reads) */
+	if (getenv("BWB_ITER_BUDGET")) budget = (uint32_t)strtoul(getenv("BWB_ITER_BUDGET"), nullptr, 10);
+	rc = launch_search(c, 0, nullptr, c->n_reads, budget, 1);
 	if (rc) return rc;
 	std::vector<uint32_t> ids;
+	if (budget) {
+		rc = collect(c, ST_HEAVY, ids);
+		if (rc) return rc;
+		if (!ids.empty()) {
+			c->stats.n_heavy_reads = ids.size();
+			rc = launch_search(c, 0, c->d_worklist, (uint32_t)ids.size(), 0, 8);
+			if (rc) return rc;
+		}
+	}
+	rc = rerun_out_overflow(c, 0);
+	if (rc) return rc;
 	for (int k = 1; k <= 2; k++) {
 		rc = collect(c, ST_SCRATCH_OVF, ids);
 		if (rc) return rc;

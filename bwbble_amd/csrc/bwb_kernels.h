@@ -17,6 +17,7 @@
 #define ST_OK 0
 #define ST_SCRATCH_OVF 1  /* heap arena / interval list / hit list too small: re-run in a bigger class */
 #define ST_OUT_OVF 2      /* global hit buffer full: host grows it and re-runs the read */
+#define ST_HEAVY 3        /* exceeded the phase-1 iteration budget: restarted in the heavy-read pass */
 
 struct KParams {
 	int max_diff, max_gapo, max_gape, max_entries;
@@ -36,6 +37,8 @@ struct Batch {
 	uint32_t *counter;        /* work-stealing cursor */
 	uint8_t *status;          /* per read */
 	uint32_t *dbg_iters;      /* optional (BWB_DEBUG): loop iterations spent on each read */
+	uint32_t iter_budget;     /* k_search: a read that needs more loop iterations than this is parked as ST_HEAVY (0 = unlimited) */
+	uint32_t lane_stride;     /* k_search: only lanes with lane % lane_stride == 0 take reads (8 => one read per octet: cooperative rank) */
 };
 
 struct OutBuf {

@@ -91,6 +91,9 @@ __device__ __forceinline__ P lane_val(const LaneReq<P> &r, const P *brow, const 
 	return brow[j] + (r.regular ? (P)(cw[4 * s + comp] + pop[j]) : (P)0);
 }
 
+#ifndef COOP_MAX_REQ
+#define COOP_MAX_REQ 16 /* lanes of a wave needing a rank at or below which the cooperative (octet) rank is used */
+#endif
 #define KID_ROWS 20 /* rows 1..15: children with exact counts; rows 16..19: O_alphabet's values for codes 5, 9, 11, 13 */
 
 /* Children of the SA interval [iL, iU], staged in LDS (one column per lane):
@@ -138,6 +141,55 @@ __device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb
 }
 /* LDS row of child j under O_alphabet semantics */
 __device__ __forceinline__ int alpha_row(int j) { return j == 5 ? 16 : (j == 9 ? 17 : (j == 11 ? 18 : (j == 13 ? 19 : j))); }
+
+/* Cooperative version for a wave in which at most 8 lanes need a rank (the drain phase of a batch, where the
+ * kernel time is the serial chain of the heaviest reads): octet k of the wave serves the k-th such lane with the
+ * octet rank of bwb_device.h (one coalesced 128-byte load per bucket, ~1/8 of the ALU work per lane) and writes the
+ * children straight into the owner's LDS columns.  Executed by all 64 lanes.  Returns the owner's ne mask
+ * (same encoding as lane_children) in the owner lane. */
+template <typename P>
+__device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buckets, P last_row, const P *s_base, unsigned long long rmask,
+                                                  unsigned long long round_mask, int round_base, bool need_rank, P iL, P iU, Lds<P> kids, int lane) {
+	const int k = lane >> 3, ol = lane & 7;
+	unsigned long long m = round_mask; /* requests not yet served: this round takes the 8 lowest */
+#pragma unroll
+	for (int t = 0; t < 7; t++) if (t < k) m &= m - 1;
+	const bool valid = m != 0;
+	const int o = valid ? __ffsll((long long)m) - 1 : 0;                       /* owner lane served by this octet */
+	P pL = oct_bcast((P)(iL - 1), o), pU = oct_bcast(iU, o);
+	if (!valid) { pL = (P)~(P)0; pU = (P)~(P)0; }
+	RankReq<P> ra, rb;
+	rank_issue<P>(buckets, last_row, pL, ol, ra);
+	rank_issue<P>(buckets, last_row, pU, ol, rb);
+	P a0, a1, u0, u1;
+	uint32_t fL = 0, fU = 0;
+	rank_finish<P, false>(ra, s_base, ol, lane, a0, a1, &fL);
+	rank_finish<P, false>(rb, s_base, ol, lane, u0, u1, &fU);
+	const int col = (int)(threadIdx.x & ~63u) + o;
+	Lds<P> kL = kids + col, kU = kids + KID_ROWS * LANE_BLOCK + col;
+	const int j0 = 2 * ol, j1 = 2 * ol + 1;
+	const P L0 = a0 + 1, L1 = a1 + 1;
+	uint32_t bits = 0;
+	if (valid) {
+		if (j0 >= 1) { kL[j0 * LANE_BLOCK] = L0; kU[j0 * LANE_BLOCK] = u0; bits |= (L0 <= u0 ? 0x10001u : 0u) << j0; }
+		kL[j1 * LANE_BLOCK] = L1; kU[j1 * LANE_BLOCK] = u1;
+		const bool quirk_code = j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13;
+		bits |= (L1 <= u1 ? (quirk_code ? 1u : 0x10001u) : 0u) << j1;
+		if (quirk_code) { /* O_alphabet's view of this code (bwt.c:427-435,780); exact in the special-cased positions */
+			const P cn = s_base[BWB_ROW_NEG * 16 + j1];
+			const P qL = ra.regular ? (P)(cn - (fL == (uint32_t)j1 ? 1 : 0) + 1) : L1;
+			const P qU = rb.regular ? (P)(cn - (fU == (uint32_t)j1 ? 1 : 0)) : u1;
+			const int row = alpha_row(j1);
+			kL[row * LANE_BLOCK] = qL; kU[row * LANE_BLOCK] = qU;
+			bits |= (qL <= qU ? 1u : 0u) << (16 + j1);
+		}
+	}
+	bits = oct_or(bits);
+	/* hand the mask to the owner: it is the r-th requesting lane, served in round r/8 by octet r%8 */
+	const int myrank = __popcll(rmask & ((1ull << lane) - 1ull));
+	const uint32_t got = oct_bcast(bits, (myrank & 7) * 8);
+	return (need_rank && (myrank >> 3) == (round_base >> 3)) ? got : 0u;
+}
 
 /* ---- SA-interval list being built: add_sa_interval (align.c:93-110), tail in registers ------------ */
 template <typename P> struct ListW {
@@ -418,7 +470,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 	h.reset();
 	for (int k = 0; k < nb; k++) h.bstate[(size_t)k * h.nslots] = NONE32;
 
-	bool active = false, done = false;
+	bool active = false, done = (threadIdx.x % b.lane_stride) != 0; /* helper-only lanes in the heavy-read pass */
 	uint32_t rid = 0;
 	int len = 0, mode = LMODE_POP;
 	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
@@ -468,12 +520,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 			}
 		}
 		if (__all(done)) break;
-		if (!active) continue;
 
 		bool finish = false, ovf = false, from_pop = false, need_rank = false;
 		P iL = 0, iU = 0;
 		int widx = 0;
-		n_iter++; r_iter++;
+		if (active) { n_iter++; r_iter++; }
 
 		/* add_alignment (align.c:271-298) into the lane's private hit list */
 		auto add_aln = [&](P L, P U, int score, int alen) {
@@ -492,7 +543,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 
 		STAMP(0);
 		/* ---- A: pick the SA interval of this iteration ---- */
-		if (mode == LMODE_POP) {
+		if (!active) { /* idle lanes only help with the cooperative rank below */ }
+		else if (mode == LMODE_POP) {
 			if (h.num_entries == 0 || h.num_entries > kp.max_entries) finish = true; /* :293,299 */
 			else {
 				/* heap_pop :594-610 */
@@ -528,10 +580,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 		const int e_state = (int)(e.sa & 3u);
 		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
 		uint32_t stX = NONE32, stG = NONE32;
+		const unsigned long long rmask = __ballot(need_rank);
+		const int nreq = __popcll(rmask);
 		if (need_rank) {
-			LaneReq<P> ra, rb;
-			lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
-			lane_issue<P>(buckets, last_row, iU, rb);
 			wd = Wd[widx]; ws = Ws[widx];
 			const int cf = seq[len - widx]; /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
@@ -539,14 +590,28 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 				stX = h.bstate[(size_t)(scX < nb ? scX : nb - 1) * h.nslots];
 				stG = h.bstate[(size_t)(scG < nb ? scG : nb - 1) * h.nslots];
 			}
-			nvis = (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
-			STAMP(2);
-			ne = lane_children<P>(ra, rb, s_base, kidL, kidU);
+			const P pl = (P)(iL - 1);
+			nvis = ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
+		}
+		STAMP(2);
+		if (nreq > COOP_MAX_REQ) {
+			if (need_rank) {
+				LaneReq<P> ra, rb;
+				lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
+				lane_issue<P>(buckets, last_row, iU, rb);
+				ne = lane_children<P>(ra, rb, s_base, kidL, kidU);
+			}
+		} else if (nreq > 0) {
+			unsigned long long rm = rmask;
+			for (int base = 0; base < nreq; base += 8) {
+				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, iL, iU, kids, (int)(threadIdx.x & 63u));
+				for (int t = 0; t < 8; t++) rm &= rm - 1;
+			}
 		}
 		STAMP(3);
 
 		/* ---- C: act on it ---- */
-		bool exact_step = (mode == LMODE_EXACT);
+		bool exact_step = active && (mode == LMODE_EXACT);
 		if (from_pop) {
 			const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
 			const int e_alen = (int)((e.sa >> 2) & 255u);
@@ -714,20 +779,22 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 		}
 
 		STAMP(5);
+		bool heavy = false;
+		if (active && !finish && !ovf && b.iter_budget && r_iter > b.iter_budget) { heavy = true; finish = true; }
 		if (ovf) finish = true;
 		if (finish) {
 			unsigned long long off = 0;
 			bool outovf = false;
-			if (!ovf && n_alns > 0) {
+			if (!ovf && !heavy && n_alns > 0) {
 				off = atomicAdd(out.count, (unsigned long long)n_alns);
 				if (off + (unsigned long long)n_alns > out.cap) outovf = true;
 				else for (int t = 0; t < n_alns * 2; t++) out.alns[off * 2 + t] = myalns[t];
 			}
 			out.off[rid] = off;
-			out.n[rid] = (ovf || outovf) ? 0u : (uint32_t)n_alns;
-			b.status[rid] = ovf ? ST_SCRATCH_OVF : (outovf ? ST_OUT_OVF : ST_OK);
+			out.n[rid] = (ovf || outovf || heavy) ? 0u : (uint32_t)n_alns;
+			b.status[rid] = ovf ? ST_SCRATCH_OVF : (heavy ? ST_HEAVY : (outovf ? ST_OUT_OVF : ST_OK));
 			if (b.dbg_iters) b.dbg_iters[rid] = r_iter;
-			if (!ovf && !outovf) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
+			if (!ovf && !outovf && !heavy) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
 			/* leave every bucket state empty for the next read */
 			h.bstate[(size_t)h.cb * h.nslots] = NONE32;
 			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[(size_t)k * h.nslots] = NONE32; h.unmark(k); }

@@ -64,6 +64,7 @@ typedef struct {
 	uint64_t heap_pops, heap_pushes;
 	uint64_t n_alignments;
 	uint64_t n_overflow_reads;   /* reads re-run with a larger scratch class (still on the GPU) */
+	uint64_t n_heavy_reads;      /* reads that exceeded the phase-1 iteration budget and were restarted in the heavy pass */
 	double ms_calc_d;            /* HIP-event time of the calculate_d kernel(s) */
 	double ms_search;            /* HIP-event time of the inexact-search kernel(s), all passes */
 	double ms_total;             /* first launch .. last kernel done */
