@@ -64,6 +64,7 @@ struct bwb_hip_ctx {
 	size_t pool_bytes = 0;
 	unsigned int *d_pool_bump = nullptr;
 	uint32_t *d_dbg_iters = nullptr;    /* BWB_DEBUG_ITERS: per-read iteration counts */
+	int bpc_search = 2, bpc_calcd = 2;
 	bool wide = false;                  /* 32-byte heap entries (64-bit positions or max_gapo > 1) */
 	std::vector<uint8_t> h_status;
 	std::vector<uint64_t> h_aln_off;
@@ -196,10 +197,11 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	ScratchClass &s = c->cls[k];
 	uint32_t blocks, lcap, acap;
 	if (k == 0) {
-		int bpc = 2; /* 8 waves per CU: measured best (1 block: 2129 ms, 2 blocks: 1645 ms on the chr21-scale -n 3 batch) */
-		if (getenv("BWB_BLOCKS_PER_CU")) bpc = atoi(getenv("BWB_BLOCKS_PER_CU"));
-		if (bpc < 1) bpc = 1;
-		blocks = (uint32_t)(c->num_cu * bpc); lcap = 1024; acap = 64;
+		/* 2 blocks (8 waves) per CU for both kernels (a third kl_calc_d block per CU measured no faster) */
+		c->bpc_search = 2; c->bpc_calcd = 2;
+		if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
+		if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
+		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 1024; acap = 64;
 	} else if (k == 1) {
 		blocks = 64; lcap = 32768; acap = 2048;
 	} else {
@@ -314,7 +316,8 @@ static int launch_calc_d(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	ScratchClass &s = c->cls[k];
 	Batch b = make_batch(c, wl, n_work);
 	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
-	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
+	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_calcd) : s.blocks;
+	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
 	const size_t lds = lane_lds(c);
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	if (c->pos32)
@@ -362,7 +365,8 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
 	HIPCHK(hipMemsetAsync(c->d_pool_bump, 0, 4, c->stream)); /* every launch starts with an empty chunk pool */
 	const uint32_t per_block = LANE_BLOCK / lane_stride;
-	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + per_block - 1) / per_block));
+	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_search) : s.blocks;
+	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + per_block - 1) / per_block));
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	if (c->pos32 && !c->wide)
 		hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);

@@ -94,26 +94,28 @@ __device__ __forceinline__ P lane_val(const LaneReq<P> &r, const P *brow, const 
 #ifndef COOP_MAX_REQ
 #define COOP_MAX_REQ 16 /* lanes of a wave needing a rank at or below which the cooperative (octet) rank is used */
 #endif
-#define KID_ROWS 20 /* rows 1..15: children with exact counts; rows 16..19: O_alphabet's values for codes 5, 9, 11, 13 */
+#define KID_ROWS 16
 
-/* Children of the SA interval [iL, iU], staged in LDS (one column per lane):
- *   rows 1..15 : child j = [C[j]+Occ(j,iL-1)+1, C[j]+Occ(j,iU)]                  (O(), bwt.c:348-372)
- *   rows 16..19: the same for j = 5, 9, 11, 13 as O_alphabet computes them        (bwt.c:427-435,780)
- * Returns ne_exact | ne_alphabet << 16: bit j = child j non-empty under either semantics. */
+/* Children of the SA interval [iL, iU], staged in LDS (one column per lane): child j = [vL(j) + 1, vU(j)], j = 1..15.
+ *   alpha == false: v(j) = C[j] + Occ(j, pos)                                      (O(), bwt.c:348-372)
+ *   alpha == true : O_alphabet (bwt.c:374-438): codes 5, 9, 11, 13 are not counted, v(j) = C[j] - [first char of the
+ *                   block == j] (bwt.c:427-435,780); exact in the special-cased positions -1 and length-1.
+ * Which of the two a visit needs is known before the rank: alpha for an expansion (inexact_match.c:382-383), exact for
+ * calculate_d / the exact tail.  Returns the bitmask of non-empty children (bits 1..15). */
 template <typename P>
-__device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb, const P *s_base, Lds<P> kidL, Lds<P> kidU) {
+__device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb, const P *s_base, bool alpha, Lds<P> kidL, Lds<P> kidU) {
 	uint32_t pop[16];
 	const P *cneg = s_base + BWB_ROW_NEG * 16;
 	{ /* L side: value + 1 (inc = 1, inexact_match.c:382) */
 		lane_pops<P>(ra, pop);
 		const P *brow = s_base + ra.row * 16;
 		const uint32_t first = (ra.d[4].x & 1u) | ((ra.d[4].y & 1u) << 1) | ((ra.d[4].z & 1u) << 2) | ((ra.d[4].w & 1u) << 3);
+		const bool q = alpha && ra.regular;
 #pragma unroll
-		for (int j = 1; j < 16; j++) kidL[j * LANE_BLOCK] = lane_val<P>(ra, brow, pop, j) + 1;
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const int j = q == 0 ? 5 : (q == 1 ? 9 : (q == 2 ? 11 : 13));
-			kidL[(16 + q) * LANE_BLOCK] = ra.regular ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0) + 1) : (P)(lane_val<P>(ra, brow, pop, j) + 1);
+		for (int j = 1; j < 16; j++) {
+			P v = lane_val<P>(ra, brow, pop, j);
+			if (j == 5 || j == 9 || j == 11 || j == 13) v = q ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : v;
+			kidL[j * LANE_BLOCK] = v + 1;
 		}
 	}
 	uint32_t ne = 0;
@@ -121,35 +123,26 @@ __device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb
 		lane_pops<P>(rb, pop);
 		const P *brow = s_base + rb.row * 16;
 		const uint32_t first = (rb.d[4].x & 1u) | ((rb.d[4].y & 1u) << 1) | ((rb.d[4].z & 1u) << 2) | ((rb.d[4].w & 1u) << 3);
+		const bool q = alpha && rb.regular;
 #pragma unroll
 		for (int j = 1; j < 16; j++) {
-			const P U = lane_val<P>(rb, brow, pop, j);
+			P U = lane_val<P>(rb, brow, pop, j);
+			if (j == 5 || j == 9 || j == 11 || j == 13) U = q ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : U;
 			kidU[j * LANE_BLOCK] = U;
-			const uint32_t bit = kidL[j * LANE_BLOCK] <= U ? 1u : 0u;
-			ne |= bit << j;
-			if (!(j == 5 || j == 9 || j == 11 || j == 13)) ne |= bit << (16 + j);
-		}
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const int j = q == 0 ? 5 : (q == 1 ? 9 : (q == 2 ? 11 : 13));
-			const P U = rb.regular ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : lane_val<P>(rb, brow, pop, j);
-			kidU[(16 + q) * LANE_BLOCK] = U;
-			ne |= (kidL[(16 + q) * LANE_BLOCK] <= U ? 1u : 0u) << (16 + j);
+			ne |= (kidL[j * LANE_BLOCK] <= U ? 1u : 0u) << j;
 		}
 	}
 	return ne;
 }
-/* LDS row of child j under O_alphabet semantics */
-__device__ __forceinline__ int alpha_row(int j) { return j == 5 ? 16 : (j == 9 ? 17 : (j == 11 ? 18 : (j == 13 ? 19 : j))); }
 
-/* Cooperative version for a wave in which at most 8 lanes need a rank (the drain phase of a batch, where the
- * kernel time is the serial chain of the heaviest reads): octet k of the wave serves the k-th such lane with the
- * octet rank of bwb_device.h (one coalesced 128-byte load per bucket, ~1/8 of the ALU work per lane) and writes the
- * children straight into the owner's LDS columns.  Executed by all 64 lanes.  Returns the owner's ne mask
- * (same encoding as lane_children) in the owner lane. */
+/* Cooperative version for a wave in which at most COOP_MAX_REQ lanes need a rank (the drain phase of a batch, where the
+ * kernel time is the serial chain of the heaviest reads): octet k of the wave serves the k-th such lane with the octet
+ * rank of bwb_device.h (one coalesced 128-byte load per bucket, ~1/8 of the ALU work per lane) and writes the children
+ * straight into the owner's LDS columns.  Executed by all 64 lanes.  Returns the owner's ne mask in the owner lane. */
 template <typename P>
 __device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buckets, P last_row, const P *s_base, unsigned long long rmask,
-                                                  unsigned long long round_mask, int round_base, bool need_rank, P iL, P iU, Lds<P> kids, int lane) {
+                                                  unsigned long long round_mask, int round_base, bool need_rank, bool alpha, P iL, P iU,
+                                                  Lds<P> kids, int lane) {
 	const int k = lane >> 3, ol = lane & 7;
 	unsigned long long m = round_mask; /* requests not yet served: this round takes the 8 lowest */
 #pragma unroll
@@ -157,6 +150,7 @@ __device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buck
 	const bool valid = m != 0;
 	const int o = valid ? __ffsll((long long)m) - 1 : 0;                       /* owner lane served by this octet */
 	P pL = oct_bcast((P)(iL - 1), o), pU = oct_bcast(iU, o);
+	const bool oalpha = oct_bcast((uint32_t)alpha, o) != 0;
 	if (!valid) { pL = (P)~(P)0; pU = (P)~(P)0; }
 	RankReq<P> ra, rb;
 	rank_issue<P>(buckets, last_row, pL, ol, ra);
@@ -168,21 +162,17 @@ __device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buck
 	const int col = (int)(threadIdx.x & ~63u) + o;
 	Lds<P> kL = kids + col, kU = kids + KID_ROWS * LANE_BLOCK + col;
 	const int j0 = 2 * ol, j1 = 2 * ol + 1;
+	if (oalpha && (j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13)) { /* O_alphabet's view of the uncounted codes */
+		const P cn = s_base[BWB_ROW_NEG * 16 + j1];
+		if (ra.regular) a1 = (P)(cn - (fL == (uint32_t)j1 ? 1 : 0));
+		if (rb.regular) u1 = (P)(cn - (fU == (uint32_t)j1 ? 1 : 0));
+	}
 	const P L0 = a0 + 1, L1 = a1 + 1;
 	uint32_t bits = 0;
 	if (valid) {
-		if (j0 >= 1) { kL[j0 * LANE_BLOCK] = L0; kU[j0 * LANE_BLOCK] = u0; bits |= (L0 <= u0 ? 0x10001u : 0u) << j0; }
+		if (j0 >= 1) { kL[j0 * LANE_BLOCK] = L0; kU[j0 * LANE_BLOCK] = u0; bits |= (L0 <= u0 ? 1u : 0u) << j0; }
 		kL[j1 * LANE_BLOCK] = L1; kU[j1 * LANE_BLOCK] = u1;
-		const bool quirk_code = j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13;
-		bits |= (L1 <= u1 ? (quirk_code ? 1u : 0x10001u) : 0u) << j1;
-		if (quirk_code) { /* O_alphabet's view of this code (bwt.c:427-435,780); exact in the special-cased positions */
-			const P cn = s_base[BWB_ROW_NEG * 16 + j1];
-			const P qL = ra.regular ? (P)(cn - (fL == (uint32_t)j1 ? 1 : 0) + 1) : L1;
-			const P qU = rb.regular ? (P)(cn - (fU == (uint32_t)j1 ? 1 : 0)) : u1;
-			const int row = alpha_row(j1);
-			kL[row * LANE_BLOCK] = qL; kU[row * LANE_BLOCK] = qU;
-			bits |= (qL <= qU ? 1u : 0u) << (16 + j1);
-		}
+		bits |= (L1 <= u1 ? 1u : 0u) << j1;
 	}
 	bits = oct_or(bits);
 	/* hand the mask to the owner: it is the r-th requesting lane, served in round r/8 by octet r%8 */
@@ -277,7 +267,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
 			lane_issue<P>(buckets, last_row, iU, rb);
 			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
-			uint32_t ne = lane_children<P>(ra, rb, s_base, kidL, kidU);
+			uint32_t ne = lane_children<P>(ra, rb, s_base, false, kidL, kidU);
 			ne &= member_mask(c);
 			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
 				const int j = __ffs((int)ne) - 1;
@@ -450,7 +440,7 @@ template <typename P, bool WIDE> struct LHeap {
 #endif
 
 template <typename P, bool WIDE>
-__global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b, KParams kp, LaneScratch sc, OutBuf out, unsigned long long *stats) {
+__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b, KParams kp, LaneScratch sc, OutBuf out, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
 	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
@@ -463,6 +453,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 	const int nb = kp.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
 	const P last_row = (P)(ix.length - 1);
+	constexpr int ESZ = WIDE ? 2 : 1; /* uint4 per heap entry */
 
 	LHeap<P, WIDE> h;
 	h.pool = sc.pool; h.pool_bump = sc.pool_bump; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
@@ -478,12 +469,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 	P cL = 0, cU = 0;
 	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
+	h.top = e;
 	int e_score = 0;
-	/* "hot" entry: the last child pushed on the bucket being popped stays in registers; it is exactly the entry the
-	 * next heap_pop returns (LIFO inside the best bucket, inexact_match.c:594-597), so chains of matches never go
-	 * through memory.  It is counted in num_entries and in the non-empty bitmap like any other entry. */
-	LEntry<P> hot = e;
-	bool hot_valid = false;
 	const uint16_t *Wd = (const uint16_t *)b.dbuf, *Ws = Wd;
 	const uint8_t *seq = b.reads;
 	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
@@ -507,21 +494,23 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 				Ws = (const uint16_t *)(b.dbuf + (size_t)rid * b.dstride + b.dseed_off);
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
-				hot_valid = false;
 				n_alns = 0; mode = LMODE_POP; active = true;
+				bool ovf0 = false;
 				if (!(cntN > kp.max_diff || len == 0)) { /* inexact_match.c:260-266 */
 					/* heap_push(root) inexact_match.c:281 */
-					hot.L = 0; hot.U = last_row; hot.f = (uint32_t)len; hot.sa = 0; hot.runsLo = hot.runsHi = ~0u;
-					hot_valid = true; h.neLo = 1; h.num_entries = 1;
+					LEntry<P> root; root.L = 0; root.U = last_row; root.f = (uint32_t)len; root.sa = 0; root.runsLo = root.runsHi = ~0u;
+					h.cst = h.reserve(NONE32, 1, ovf0);
+					if (!ovf0) { h.cst++; h.store_entry(h.cst, root); h.top = root; h.top_valid = true; h.mark(0); h.num_entries = 1; }
 					r_push++;
 				}
 				best_score = kp.num_buckets; /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
 				max_diff = kp.max_diff; num_best = 0;
+				if (ovf0) { b.status[rid] = ST_SCRATCH_OVF; out.n[rid] = 0; active = false; }
 			}
 		}
 		if (__all(done)) break;
 
-		bool finish = false, ovf = false, from_pop = false, need_rank = false;
+		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false;
 		P iL = 0, iU = 0;
 		int widx = 0;
 		if (active) { n_iter++; r_iter++; }
@@ -547,22 +536,21 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 		else if (mode == LMODE_POP) {
 			if (h.num_entries == 0 || h.num_entries > kp.max_entries) finish = true; /* :293,299 */
 			else {
-				/* heap_pop :594-610 */
-				if (hot_valid) {
-					e = hot; hot_valid = false; h.num_entries--; /* e_score stays: the hot entry lives on the bucket just popped */
-					if (h.cst == NONE32) h.unmark(h.cb);
-				} else {
-					const int bk = h.best(nb);
-					h.switch_cache(bk);
-					h.pop(e);
-				}
-				e_score = h.cb;
+				const int bk = h.best(nb);
+				h.switch_cache(bk);
+				h.pop(e); /* heap_pop :594-610: the top of the best bucket, usually straight from its register mirror */
+				e_score = bk;
 				r_pop++;
 				if (e_score > best_score + kp.mm_score) finish = true; /* :309 */
 				else {
 					from_pop = true;
 					widx = (int)(e.f & 255u);
-					if (widx > 0) { need_rank = true; iL = e.L; iU = e.U; }
+					if (widx > 0) {
+						need_rank = true; iL = e.L; iU = e.U;
+						/* an entry with no difference left goes to the exact tail (exact counts); any other one is expanded
+						 * with O_alphabet (:345,382) */
+						alpha = (max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0;
+					}
 				}
 			}
 		} else { /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
@@ -599,12 +587,12 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 				LaneReq<P> ra, rb;
 				lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
 				lane_issue<P>(buckets, last_row, iU, rb);
-				ne = lane_children<P>(ra, rb, s_base, kidL, kidU);
+				ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
 			}
 		} else if (nreq > 0) {
 			unsigned long long rm = rmask;
 			for (int base = 0; base < nreq; base += 8) {
-				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, iL, iU, kids, (int)(threadIdx.x & 63u));
+				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, alpha, iL, iU, kids, (int)(threadIdx.x & 63u));
 				for (int t = 0; t < 8; t++) rm &= rm - 1;
 			}
 		}
@@ -639,7 +627,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 				} else {
 					/* ---- expansion :377-504 ---- */
 					r_vis_a += nvis;
-					const uint32_t nea = ne >> 16; /* non-empty children under O_alphabet semantics */
 					bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
 					if (e_i - 1 > 0) {
 						const int d1 = wd & 255u, d2 = (wd >> 8) & 255u;
@@ -662,19 +649,17 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 					const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
 					const bool mm_ok = allow_diff && allow_mm;
 					const uint32_t mem = cr > 3 ? 0u : member_mask(cr);
-					/* push sequence (:434-504): bit 0 insertion, bits 1..15 deletions j, bits 16+j match/mismatch j */
-					const uint32_t gapm = (ins_ok ? 1u : 0u) | (del_ok ? nea : 0u);
-					const uint32_t mgrp = mm_ok ? nea : (nea & mem);
+					/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
+					const uint32_t gapm = (ins_ok ? 1u : 0u) | (del_ok ? ne : 0u);
+					const uint32_t mgrp = mm_ok ? ne : (ne & mem);
 					const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
-					uint32_t seqm = gapm | (mgrp << 16);
-					r_push += __popc(seqm);
+					const int nG = __popc(gapm), nX = __popc(mism), n0 = __popc(matchm);
+					r_push += nG + nX + n0;
 					/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
 					const int tX = scX == sc0 ? 0 : 1, tG = scG == sc0 ? 0 : (scG == scX ? tX : 2);
-					const uint32_t m0 = (matchm << 16) | (tX == 0 ? mism << 16 : 0u) | (tG == 0 ? gapm : 0u);
-					const int hotbit = m0 ? 31 - __clz((int)m0) : -1;     /* the last entry landing on sc0 stays in registers */
-					const int k0 = __popc(m0) - (m0 ? 1 : 0);
-					const int k1 = (tX == 1 ? __popc(mism) : 0) + (tG == 1 ? __popc(gapm) : 0);
-					const int k2 = tG == 2 ? __popc(gapm) : 0;
+					const int k0 = n0 + (tX == 0 ? nX : 0) + (tG == 0 ? nG : 0);
+					const int k1 = (tX == 1 ? nX : 0) + (tG == 1 ? nG : 0);
+					const int k2 = tG == 2 ? nG : 0;
 					uint32_t st0 = h.reserve(h.cst, k0, ovf);
 					uint32_t st1 = h.reserve(stX, k1, ovf);
 					uint32_t st2 = h.reserve(stG, k2, ovf);
@@ -693,34 +678,60 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 							gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
 							gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
 						} else gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
-						LEntry<P> ch;
-						while (seqm) {
-							const int q = __ffs((int)seqm) - 1;
-							seqm &= seqm - 1;
-							const bool isgap = q < 16, is_ins = q == 0;
-							const int j = q & 15;
-							const bool is_mis = !isgap && !((mem >> j) & 1u);
-							const int row = alpha_row(j);
-							ch.L = is_ins ? e.L : kidL[row * LANE_BLOCK];
-							ch.U = is_ins ? e.U : kidU[row * LANE_BLOCK];
-							ch.f = isgap ? (f_gap | (uint32_t)((is_ins ? e_i - 1 : e_i) & 255)) : (is_mis ? f_mis : f_match);
-							ch.sa = (isgap ? (is_ins ? STATE_I : STATE_D) : STATE_M) | (alen1 << 2);
-							const uint64_t rr = isgap ? (is_ins ? gruns_i : gruns_d) : eruns;
-							ch.runsLo = (uint32_t)rr; ch.runsHi = (uint32_t)(rr >> 32);
-							const int t = isgap ? tG : (is_mis ? tX : 0);
-							if (q == hotbit) { hot = ch; hot_valid = true; }
-							else {
-								uint32_t st = t == 0 ? st0 : (t == 1 ? st1 : st2);
-								st++;
-								h.store_entry(st, ch);
-								if (t == 0) { st0 = st; h.top = ch; } else if (t == 1) st1 = st; else st2 = st;
+						/* next free slot of every target bucket */
+						uint4 *p0 = h.chunk_ptr(st0 >> 6) + ((st0 & 63u) + 1) * ESZ;
+						uint4 *p1 = h.chunk_ptr(st1 >> 6) + ((st1 & 63u) + 1) * ESZ;
+						uint4 *p2 = h.chunk_ptr(st2 >> 6) + ((st2 & 63u) + 1) * ESZ;
+						auto emit = [&](uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+							if (WIDE) {
+								p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
+								p[1] = make_uint4(f, sa, (uint32_t)runs, (uint32_t)(runs >> 32));
+							} else p[0] = make_uint4((uint32_t)L, (uint32_t)U, f, sa | ((uint32_t)runs << 10));
+							p += ESZ;
+						};
+						bool top_ok = false; /* does h.top mirror the last entry stored on bucket sc0? */
+						{ /* gap pushes: insertion (keeps the interval), then deletions in code order */
+							uint4 *pg = tG == 0 ? p0 : (tG == 1 ? p1 : p2);
+							uint32_t gm = gapm;
+							if (gm & 1u) { emit(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i); gm &= ~1u; }
+							const uint32_t fd = f_gap | (uint32_t)(e_i & 255), sd = (uint32_t)STATE_D | (alen1 << 2);
+							while (gm) {
+								const int j = __ffs((int)gm) - 1;
+								gm &= gm - 1;
+								emit(pg, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], fd, sd, gruns_d);
+							}
+							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
+						}
+						const uint32_t sm = (uint32_t)STATE_M | (alen1 << 2);
+						if (kp.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
+							uint4 *px = tX == 1 ? p1 : p0;
+							uint32_t xm = mism;
+							while (xm) {
+								const int j = __ffs((int)xm) - 1;
+								xm &= xm - 1;
+								emit(px, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], f_mis, sm, eruns);
+							}
+							if (tX == 1) p1 = px; else p0 = px;
+							uint32_t mm = matchm;
+							while (mm) {
+								const int j = __ffs((int)mm) - 1;
+								mm &= mm - 1;
+								h.top.L = kidL[j * LANE_BLOCK]; h.top.U = kidU[j * LANE_BLOCK];
+								emit(p0, h.top.L, h.top.U, f_match, sm, eruns);
+							}
+							if (matchm) { h.top.f = f_match; h.top.sa = sm; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi; top_ok = true; }
+						} else { /* mm_score == 0: one bucket, interleaved in code order */
+							uint32_t am = mgrp;
+							while (am) {
+								const int j = __ffs((int)am) - 1;
+								am &= am - 1;
+								emit(p0, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
 							}
 						}
-						h.num_entries += __popc(gapm) + __popc(mgrp);
-						if (m0) h.mark(sc0);
-						if (k0 > 0) { h.cst = st0; h.top_valid = true; }
-						if (k1 > 0) { h.bstate[(size_t)(tX == 1 ? scX : scG) * h.nslots] = st1; h.mark(tX == 1 ? scX : scG); }
-						if (k2 > 0) { h.bstate[(size_t)scG * h.nslots] = st2; h.mark(scG); }
+						h.num_entries += nG + nX + n0;
+						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; }
+						if (k1 > 0) { h.bstate[(size_t)scX * h.nslots] = st1 + (uint32_t)k1; h.mark(scX); }
+						if (k2 > 0) { h.bstate[(size_t)scG * h.nslots] = st2 + (uint32_t)k2; h.mark(scG); }
 					}
 				}
 			}
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 1) void kl_search(DevIndex ix, Batch b,
 			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
 			else {
 				r_vis_s += nvis;
-				uint32_t nm = ne & 0xFFFFu & member_mask(cr);
+				uint32_t nm = ne & member_mask(cr);
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;
