@@ -466,10 +466,10 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	hipEventDestroy(t0); hipEventDestroy(t1);
 	unsigned long long st[16];
 	HIPCHK(hipMemcpy(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
-	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA];
+	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA]; c->stats.visits_calc_d = st[STAT_VIS_CALCD];
 	c->stats.heap_pops = st[STAT_POPS]; c->stats.heap_pushes = st[STAT_PUSHES]; c->stats.n_alignments = st[STAT_ALNS];
 	if (getenv("BWB_DEBUG")) {
-		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu\n", st[STAT_N], st[STAT_N + 1]);
+		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu\n", st[STAT_N], st[STAT_N_MAX]);
 		fprintf(stderr, "[bwb] stamps (cycles): top %llu | A(pop) %llu | B(issue) %llu | C(rank) %llu | D(act) %llu | E(exact) %llu | F(finish..) %llu\n", st[8+0], st[8+1], st[8+2], st[8+3], st[8+4], st[8+5], st[8+7]);
 	}
 	c->ran = true;

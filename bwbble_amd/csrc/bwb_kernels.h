@@ -49,7 +49,7 @@ struct OutBuf {
 	uint32_t *n;              /* per read: #records */
 };
 
-enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N };
+enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N, STAT_N_MAX, STAT_VIS_CALCD };
 
 template <typename P> struct Intv { P L, U; };
 

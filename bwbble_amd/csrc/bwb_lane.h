@@ -319,7 +319,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			}
 		}
 	}
-	if (vis) atomicAdd(&stats[STAT_VIS_SINGLE], vis);
+	if (vis) { atomicAdd(&stats[STAT_VIS_SINGLE], vis); atomicAdd(&stats[STAT_VIS_CALCD], vis); }
 }
 
 /* ============================================================================================
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	if (n_push) atomicAdd(&stats[STAT_PUSHES], n_push);
 	if (n_aln_tot) atomicAdd(&stats[STAT_ALNS], n_aln_tot);
 	atomicAdd(&stats[STAT_N], n_iter);        /* debug: total loop iterations */
-	atomicMax(&stats[STAT_N + 1], n_iter);    /* debug: longest lane */
+	atomicMax(&stats[STAT_N_MAX], n_iter);    /* debug: longest lane */
 #ifdef BWB_STAMPS
 	if (n_iter) for (int k = 0; k < 8; k++) atomicAdd(&stats[8 + k], seg[k]);
 #endif

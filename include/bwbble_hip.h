@@ -60,6 +60,7 @@ typedef struct {
 /* Work/timing counters of the last batch_run (SURVEY.md 8(d) counting rules) */
 typedef struct {
 	uint64_t visits_single;      /* rank-block visits made for the 7-code exact steps (calculate_d, exact tail) */
+	uint64_t visits_calc_d;      /* the part of visits_single made by the calculate_d kernel */
 	uint64_t visits_alphabet;    /* rank-block visits made for O_alphabet (2 per expansion unless special-cased) */
 	uint64_t heap_pops, heap_pushes;
 	uint64_t n_alignments;
