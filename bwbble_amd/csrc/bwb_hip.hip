@@ -183,8 +183,9 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	size_t want = (size_t)64 << 30;
 	if (getenv("BWB_POOL_GB")) want = (size_t)atol(getenv("BWB_POOL_GB")) << 30;
 	if (want > fr / 2) want = fr / 2;
+	if (want < ((size_t)64 << 20)) want = (size_t)64 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path) */
 	want &= ~(size_t)4095;
-	if (want < ((size_t)64 << 20)) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
+	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
 	HIPCHK(hipMalloc(&c->d_pool, want));
 	HIPCHK(hipMalloc(&c->d_pool_bump, 64));
 	c->pool_bytes = want;
