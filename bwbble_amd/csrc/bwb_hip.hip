@@ -63,6 +63,7 @@ struct bwb_hip_ctx {
 	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes */
 	size_t pool_bytes = 0;
 	unsigned int *d_pool_bump = nullptr;
+	uint32_t keep = 64;
 	uint32_t *d_dbg_iters = nullptr;    /* BWB_DEBUG_ITERS: per-read iteration counts */
 	int bpc_search = 2, bpc_calcd = 2;
 	bool wide = false;                  /* 32-byte heap entries (64-bit positions or max_gapo > 1) */
@@ -201,6 +202,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 		/* 2 blocks (8 waves) per CU for both kernels (a third kl_calc_d block per CU measured no faster) */
 		c->bpc_search = 2; c->bpc_calcd = 2;
 		if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
+		if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
 		if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
 		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 1024; acap = 64;
 	} else if (k == 1) {
@@ -230,7 +232,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.alns = (uint4 *)base; base += al(b_alns);
 	s.sc.winfo = (uint2 *)base;
 	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = wstride;
-	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump;
+	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump; s.sc.keep = c->keep;
 	s.sc.pool_cap = (uint32_t)std::min<size_t>(c->pool_bytes / (c->wide ? 2048 : 1024), (size_t)1 << 26);
 	s.blocks = blocks;
 	return BWB_OK;

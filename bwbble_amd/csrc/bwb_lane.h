@@ -16,8 +16,9 @@
  * VALU-bound at ~4 us per iteration).  Lanes pull reads from a global cursor (work stealing).
  *
  * Per-lane memory (global, private to the lane while it owns a read):
- *   heap    : chains of 64-slot chunks from a shared pool (atomic bump allocation; chunks freed by
- *             pops stay on the lane's private free list).  slot 0 = header {prev chunk}.
+ *   heap    : chains of 64-slot chunks from a shared pool (atomic bump allocation); a lane keeps its first `keep`
+ *             chunks, what a read takes beyond them goes to the block's lock-free stack of recycled chunks when the
+ *             read ends.  slot 0 = header.
  *   bstate  : [bucket][slot] u32 = chunk<<6 | fill; the bucket being popped is cached in registers.
  *   lists   : two SA-interval lists (cur/next) with the open tail in registers.
  *   hits    : the read's alignments (needed for the gapped-duplicate check, align.c:273-280).
@@ -38,6 +39,7 @@ struct LaneScratch {
 	uint4 *pool;                /* chunk pool: chunk c at pool + c * CHUNK_SLOTS * (WIDE ? 2 : 1) */
 	unsigned int *pool_bump;    /* next never-used chunk */
 	uint32_t pool_cap;          /* chunks in the pool */
+	uint32_t keep;              /* chunks a lane keeps for itself across reads */
 	uint32_t *bstate;           /* [nb][nslots] */
 	void *lists;                /* [nslots][2*lcap] Intv<P> */
 	uint4 *alns;                /* [nslots][acap*2] */
@@ -337,7 +339,7 @@ template <typename P> struct LEntry {
 
 /* Score-bucketed LIFO heap (inexact_match.h:17-34, inexact_match.c:510-610): every bucket is a chain of 64-slot
  * chunks.  Chunk header (slot 0): .x = next chunk of the lane's free list, .y = state word of the bucket before this
- * chunk was started (so a chunk may be left partially filled), .z = next chunk in the lane's "owned" chain.
+ * chunk was started (so a chunk may be left partially filled), .z = next chunk in the lane's private chain / excess chain / the block's recycle stack.
  * A bucket state word is chunk<<6 | fill (fill = index of the top entry, 1..63), NONE32 when empty. */
 template <typename P, bool WIDE> struct LHeap {
 	uint4 *pool;
@@ -346,8 +348,9 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t *bstate;      /* this lane's column: bstate[s * nslots] */
 	uint32_t nslots;
 	uint32_t fhead;        /* chunks emptied by pops during this read */
-	uint32_t ohead, otail, ocur; /* every chunk this lane ever took from the pool, in allocation order; a new read
-	                                rewinds ocur, so resetting the heap costs nothing */
+	uint32_t phead, ptail, ocur, pcnt, keep; /* private chain and the walk over it */
+	uint32_t xhead, xtail;       /* chunks the current read took beyond the private chain */
+	Lds<unsigned long long> blockfree; /* head of this block's stack of recycled chunks (LDS): version<<32 | chunk */
 	uint64_t neLo, neHi;   /* non-empty buckets */
 	int cb;                /* bucket whose state is cached in registers = score of the entry last popped */
 	uint32_t cst;
@@ -356,7 +359,7 @@ template <typename P, bool WIDE> struct LHeap {
 	bool top_valid;
 
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { fhead = NONE32; ocur = ohead; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
+	__device__ __forceinline__ void reset() { fhead = NONE32; ocur = phead; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
 	__device__ __forceinline__ void mark(int s) { if (s < 64) neLo |= 1ull << s; else neHi |= 1ull << (s - 64); }
 	__device__ __forceinline__ void unmark(int s) { if (s < 64) neLo &= ~(1ull << s); else neHi &= ~(1ull << (s - 64)); }
 	__device__ __forceinline__ int best(int nb) const {
@@ -368,15 +371,49 @@ template <typename P, bool WIDE> struct LHeap {
 		cb = s; cst = bstate[(size_t)s * nslots];
 		top_valid = false;
 	}
+	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private chain (the first `keep`
+	 * chunks it ever took, header .z, rewound at every read so that an ordinary read allocates without any atomic); the
+	 * block's stack of chunks recycled by finished reads (lock-free: versioned head, so a pop cannot be fooled by a chunk
+	 * that left and came back); the pool.  What a read takes beyond the private chain is threaded on its excess chain
+	 * and goes back to the block stack in one push when the read ends, so the pool holds what the reads in flight need,
+	 * not the worst case every lane has ever seen. */
 	__device__ __forceinline__ uint32_t alloc(bool &ovf) {
 		if (fhead != NONE32) { const uint32_t c = fhead; fhead = chunk_ptr(c)[0].x; return c; }
 		if (ocur != NONE32) { const uint32_t c = ocur; ocur = chunk_ptr(c)[0].z; return c; }
-		const uint32_t c = atomicAdd(pool_bump, 1u);
-		if (c >= pool_cap) { ovf = true; return 0; }
-		chunk_ptr(c)[0].z = NONE32;
-		if (otail != NONE32) chunk_ptr(otail)[0].z = c; else ohead = c;
-		otail = c;
+		uint32_t c = NONE32;
+		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		while ((uint32_t)old != NONE32) {
+			const uint32_t top = (uint32_t)old;
+			const uint32_t nxt = __hip_atomic_load(&chunk_ptr(top)[0].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long want = (((old >> 32) + 1) << 32) | nxt;
+			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { c = top; break; }
+		}
+		if (c == NONE32) {
+			c = atomicAdd(pool_bump, 1u);
+			if (c >= pool_cap) { ovf = true; return 0; }
+		}
+		if (pcnt < keep) {
+			chunk_ptr(c)[0].z = NONE32;
+			if (ptail != NONE32) chunk_ptr(ptail)[0].z = c; else phead = c;
+			ptail = c; pcnt++;
+		} else {
+			__hip_atomic_store(&chunk_ptr(c)[0].z, xhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (xhead == NONE32) xtail = c;
+			xhead = c;
+		}
 		return c;
+	}
+	/* end of a read: hand the chunks it took beyond the private chain to the block */
+	__device__ __forceinline__ void release_excess() {
+		if (xhead == NONE32) return;
+		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		for (;;) {
+			__hip_atomic_store(&chunk_ptr(xtail)[0].z, (uint32_t)old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the link is in L2 before the head can name this chain */
+			const unsigned long long want = (((old >> 32) + 1) << 32) | xhead;
+			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+		}
+		xhead = xtail = NONE32;
 	}
 	/* makes room for k (<= 63) more entries on a bucket whose state is st; returns the state to push from */
 	__device__ __forceinline__ uint32_t reserve(uint32_t st, int k, bool &ovf) {
@@ -444,6 +481,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
 	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
+	__shared__ unsigned long long s_blockfree;
+	if (threadIdx.x == 0) s_blockfree = ~0ull;
 	load_base<P>(s_base, ix);
 	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
@@ -457,7 +496,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 
 	LHeap<P, WIDE> h;
 	h.pool = sc.pool; h.pool_bump = sc.pool_bump; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
-	h.ohead = h.otail = h.ocur = NONE32;
+	h.phead = h.ptail = h.xhead = h.xtail = NONE32; h.pcnt = 0; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
 	for (int k = 0; k < nb; k++) h.bstate[(size_t)k * h.nslots] = NONE32;
 
@@ -505,7 +544,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				}
 				best_score = kp.num_buckets; /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
 				max_diff = kp.max_diff; num_best = 0;
-				if (ovf0) { b.status[rid] = ST_SCRATCH_OVF; out.n[rid] = 0; active = false; }
+				if (ovf0) { b.status[rid] = ST_SCRATCH_OVF; out.n[rid] = 0; h.release_excess(); active = false; }
 			}
 		}
 		if (__all(done)) break;
@@ -806,7 +845,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			b.status[rid] = ovf ? ST_SCRATCH_OVF : (heavy ? ST_HEAVY : (outovf ? ST_OUT_OVF : ST_OK));
 			if (b.dbg_iters) b.dbg_iters[rid] = r_iter;
 			if (!ovf && !outovf && !heavy) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
-			/* leave every bucket state empty for the next read */
+			/* leave every bucket state empty for the next read and give its chunks back */
+			h.release_excess();
 			h.bstate[(size_t)h.cb * h.nslots] = NONE32;
 			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[(size_t)k * h.nslots] = NONE32; h.unmark(k); }
 			active = false;
