@@ -60,13 +60,13 @@ struct bwb_hip_ctx {
 	uint64_t log_cap = 0, sorted_cap = 0;
 	uint32_t dstride = 0, dseed_off = 0;
 	ScratchClass cls[3];
-	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes */
+	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes, POOL_REGIONS equal regions */
 	size_t pool_bytes = 0;
 	unsigned int *d_pool_bump = nullptr;
 	uint32_t keep = 64;
 	uint32_t *d_dbg_iters = nullptr;    /* BWB_DEBUG_ITERS: per-read iteration counts */
 	int bpc_search = 2, bpc_calcd = 2;
-	bool wide = false;                  /* 32-byte heap entries (64-bit positions or max_gapo > 1) */
+	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
 	std::vector<uint8_t> h_status;
 	std::vector<uint64_t> h_aln_off;
 	std::vector<bwb_aln> h_alns;
@@ -109,7 +109,7 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	HIPCHK(hipMalloc(&c->d_buckets, nblk * 128));
 	HIPCHK(hipMalloc(&c->d_counter, 64));
 	HIPCHK(hipMalloc(&c->d_count, 64));
-	HIPCHK(hipMalloc(&c->d_stats, sizeof(unsigned long long) * 16));
+	HIPCHK(hipMalloc(&c->d_stats, sizeof(unsigned long long) * 24));
 
 	/* superblock base table */
 	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
@@ -181,14 +181,16 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	if (c->d_pool) return BWB_OK;
 	size_t fr = 0, tot = 0;
 	hipMemGetInfo(&fr, &tot);
-	size_t want = (size_t)64 << 30;
+	/* Default: 60 % of what is free (the rest is for the scratch classes and the hit log), at most what the regions can
+	 * name: a state word holds a 26-bit chunk index relative to the block's region. */
+	size_t want = std::min<size_t>(fr / 10 * 6, (size_t)POOL_REGIONS << 36);
 	if (getenv("BWB_POOL_GB")) want = (size_t)atol(getenv("BWB_POOL_GB")) << 30;
-	if (want > fr / 2) want = fr / 2;
+	if (want > fr / 10 * 7) want = fr / 10 * 7;
 	if (want < ((size_t)64 << 20)) want = (size_t)64 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path) */
-	want &= ~(size_t)4095;
+	want &= ~(size_t)(POOL_REGIONS * 4096 - 1);
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
 	HIPCHK(hipMalloc(&c->d_pool, want));
-	HIPCHK(hipMalloc(&c->d_pool_bump, 64));
+	HIPCHK(hipMalloc(&c->d_pool_bump, POOL_REGIONS * 64));
 	c->pool_bytes = want;
 	return BWB_OK;
 }
@@ -206,7 +208,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 		if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
 		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 1024; acap = 64;
 	} else if (k == 1) {
-		blocks = 64; lcap = 32768; acap = 2048;
+		blocks = (uint32_t)c->num_cu; lcap = 8192; acap = 1024;
 	} else {
 		blocks = 4; lcap = 1u << 20; acap = 1u << 16;
 	}
@@ -233,7 +235,6 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.winfo = (uint2 *)base;
 	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = wstride;
 	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump; s.sc.keep = c->keep;
-	s.sc.pool_cap = (uint32_t)std::min<size_t>(c->pool_bytes / (c->wide ? 2048 : 1024), (size_t)1 << 26);
 	s.blocks = blocks;
 	return BWB_OK;
 }
@@ -258,7 +259,7 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
 	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb };
 	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
-	c->wide = !c->pos32 || p->max_gapo > 1;
+	c->wide = p->max_gapo > 1;
 	/* per read: u16 {D[i-1], D[i-2]} for i = 0..maxlen+1, then u16 {Dseed[si-1], Dseed[si-2]}, then the N count */
 	c->dseed_off = pad16(2 * (maxlen + 2));
 	c->dstride = 2 * c->dseed_off + 16;
@@ -366,15 +367,22 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	OutBuf ob{ c->d_log, c->d_count, c->log_cap, c->d_off, c->d_n };
 	const size_t lds = lane_lds(c);
 	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
-	HIPCHK(hipMemsetAsync(c->d_pool_bump, 0, 4, c->stream)); /* every launch starts with an empty chunk pool */
+	HIPCHK(hipMemsetAsync(c->d_pool_bump, 0, POOL_REGIONS * 64, c->stream)); /* every launch starts with an empty chunk pool */
 	const uint32_t per_block = LANE_BLOCK / lane_stride;
 	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_search) : s.blocks;
 	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + per_block - 1) / per_block));
+	/* one region per 8 blocks up to POOL_REGIONS, so that the few blocks of a small launch (class 2) are not confined to
+	 * a fraction of the pool; a state word names 2^26 chunks of its region */
+	s.sc.n_regions = std::max<uint32_t>(1, std::min<uint32_t>(POOL_REGIONS, grid / 8));
+	s.sc.region_u4 = c->pool_bytes / s.sc.n_regions / 4096 * 256;
+	s.sc.pool_cap = (uint32_t)std::min<size_t>(s.sc.region_u4 * 16 / (c->wide ? 2048 : 1024), (size_t)1 << 26);
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	if (c->pos32 && !c->wide)
 		hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
 	else if (c->pos32)
 		hipLaunchKernelGGL((kl_search<uint32_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
+	else if (!c->wide)
+		hipLaunchKernelGGL((kl_search<uint64_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
 	else
 		hipLaunchKernelGGL((kl_search<uint64_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
 	HIPCHK(hipGetLastError());
@@ -384,9 +392,11 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	c->stats.ms_search += ms; c->stats.launches_search++;
 	if (getenv("BWB_DEBUG")) {
-		unsigned int used = 0;
-		hipMemcpy(&used, c->d_pool_bump, 4, hipMemcpyDeviceToHost);
-		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, budget %u, lane stride %u, %.3f ms, pool chunks used %u of %u\n", k, n_work, grid, iter_budget, lane_stride, ms, used, s.sc.pool_cap);
+		unsigned int bump[POOL_REGIONS * 16], used_max = 0;
+		unsigned long long used = 0;
+		hipMemcpy(bump, c->d_pool_bump, sizeof(bump), hipMemcpyDeviceToHost);
+		for (uint32_t r = 0; r < s.sc.n_regions; r++) { used += std::min(bump[r * 16], s.sc.pool_cap); used_max = std::max(used_max, bump[r * 16]); }
+		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, budget %u, lane stride %u, %.3f ms, pool chunks used %llu of %d x %u (fullest region asked for %u)\n", k, n_work, grid, iter_budget, lane_stride, ms, used, (int)s.sc.n_regions, s.sc.pool_cap, used_max);
 	}
 	return BWB_OK;
 }
@@ -419,7 +429,7 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	if (!c || !c->uploaded) return fail(BWB_E_STATE, "batch_run: no batch uploaded");
 	HIPCHK(hipSetDevice(c->device));
 	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 16, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 24, c->stream));
 	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
 	if (c->n_reads == 0) { c->ran = true; return BWB_OK; }
 	HIPCHK(hipMemsetAsync(c->d_n, 0, (size_t)c->n_reads * 4, c->stream));
@@ -467,12 +477,12 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	HIPCHK(hipEventElapsedTime(&ms, t0, t1));
 	c->stats.ms_total = ms;
 	hipEventDestroy(t0); hipEventDestroy(t1);
-	unsigned long long st[16];
+	unsigned long long st[24];
 	HIPCHK(hipMemcpy(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
 	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA]; c->stats.visits_calc_d = st[STAT_VIS_CALCD];
 	c->stats.heap_pops = st[STAT_POPS]; c->stats.heap_pushes = st[STAT_PUSHES]; c->stats.n_alignments = st[STAT_ALNS];
 	if (getenv("BWB_DEBUG")) {
-		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu\n", st[STAT_N], st[STAT_N_MAX]);
+		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu, wave iterations %llu (%.1f of 64 lanes busy)\n", st[STAT_N], st[STAT_N_MAX], st[16], st[16] ? (double)st[STAT_N] / (double)st[16] : 0.0);
 		fprintf(stderr, "[bwb] stamps (cycles): top %llu | A(pop) %llu | B(issue) %llu | C(rank) %llu | D(act) %llu | E(exact) %llu | F(finish..) %llu\n", st[8+0], st[8+1], st[8+2], st[8+3], st[8+4], st[8+5], st[8+7]);
 	}
 	c->ran = true;
@@ -534,7 +544,7 @@ extern "C" int bwb_hip_calc_d(bwb_hip_ctx *c, int32_t *out_D, int32_t *out_Dseed
 	HIPCHK(hipMemset(dD, 0, (nD ? nD : 1) * 4));
 	HIPCHK(hipMemset(dS, 0, (nS ? nS : 1) * 4));
 	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 16, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 24, c->stream));
 	int rc = c->n_reads ? run_calc_d(c, dD, dS) : BWB_OK;
 	if (!rc) {
 		hipMemcpy(out_D, dD, nD * 4, hipMemcpyDeviceToHost);

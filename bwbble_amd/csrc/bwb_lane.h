@@ -34,11 +34,16 @@
  * pointer here turns every access into a flat_* instruction with 64-bit addresses and full waits) */
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define CHUNK_SLOTS 64          /* slot 0 is the header: 63 entries per chunk */
+#define POOL_REGIONS 8
+#define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 
 struct LaneScratch {
-	uint4 *pool;                /* chunk pool: chunk c at pool + c * CHUNK_SLOTS * (WIDE ? 2 : 1) */
-	unsigned int *pool_bump;    /* next never-used chunk */
-	uint32_t pool_cap;          /* chunks in the pool */
+	uint4 *pool;                /* chunk pool in POOL_REGIONS regions (block b uses region b % n_regions: its XCD's when all 8 are in use):
+	                               chunk c of a region at region base + c * CHUNK_SLOTS * (WIDE ? 2 : 1) */
+	size_t region_u4;           /* uint4 per region */
+	uint32_t n_regions;         /* regions this launch uses (<= POOL_REGIONS) */
+	unsigned int *pool_bump;    /* [POOL_REGIONS * 16] next never-used chunk of every region, 64 bytes apart */
+	uint32_t pool_cap;          /* chunks in a region */
 	uint32_t keep;              /* chunks a lane keeps for itself across reads */
 	uint32_t *bstate;           /* [nb][nslots] */
 	void *lists;                /* [nslots][2*lcap] Intv<P> */
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 /* ============================================================================================
  * k_search (one read per lane)
  * ========================================================================================== */
-/* heap entry.  NARROW (P = u32 and max_gapo <= 1): 16 bytes {L, U, i|mm|go|ge, state|alen<<2|run<<10};
+/* heap entry.  NARROW (max_gapo <= 1): 16 bytes {L lo, U lo, i|mm|go|ge, state|alen<<2|run<<10|L hi<<26|U hi<<29};
  * WIDE: 32 bytes {L, U (64-bit each)} {i|mm|go|ge, state|alen<<8, runs lo, runs hi}.
  * runs: one 16-bit word per gap open: start | len<<8 | isD<<15, 0xFFFF = unused. */
 template <typename P> struct LEntry {
@@ -351,6 +356,8 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t phead, ptail, ocur, pcnt, keep; /* private chain and the walk over it */
 	uint32_t xhead, xtail;       /* chunks the current read took beyond the private chain */
 	Lds<unsigned long long> blockfree; /* head of this block's stack of recycled chunks (LDS): version<<32 | chunk */
+	Lds<unsigned int> nfree;     /* chunks on that stack */
+	uint32_t xcnt;               /* chunks on the excess chain */
 	uint64_t neLo, neHi;   /* non-empty buckets */
 	int cb;                /* bucket whose state is cached in registers = score of the entry last popped */
 	uint32_t cst;
@@ -358,6 +365,13 @@ template <typename P, bool WIDE> struct LHeap {
 	LEntry<P> top;         /* register mirror of the entry on top of bucket cb's memory stack */
 	bool top_valid;
 
+	/* last word of a 16-byte entry: state|aln_length (10 bits), the one gap run (16), bits 32..34 of L and of U (the
+	 * superblock table covers 2^34 BWT characters, bwb_device.h) */
+	static __device__ __forceinline__ uint32_t pack_w(P L, P U, uint32_t sa, uint32_t runsLo) {
+		uint32_t w = sa | ((runsLo & 0xFFFFu) << 10);
+		if (sizeof(P) == 8) w |= ((uint32_t)((uint64_t)L >> 32) << 26) | ((uint32_t)((uint64_t)U >> 32) << 29);
+		return w;
+	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
 	__device__ __forceinline__ void reset() { fhead = NONE32; ocur = phead; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
 	__device__ __forceinline__ void mark(int s) { if (s < 64) neLo |= 1ull << s; else neHi |= 1ull << (s - 64); }
@@ -386,7 +400,7 @@ template <typename P, bool WIDE> struct LHeap {
 			const uint32_t top = (uint32_t)old;
 			const uint32_t nxt = __hip_atomic_load(&chunk_ptr(top)[0].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const unsigned long long want = (((old >> 32) + 1) << 32) | nxt;
-			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { c = top; break; }
+			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { c = top; __hip_atomic_fetch_add(nfree, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
 		}
 		if (c == NONE32) {
 			c = atomicAdd(pool_bump, 1u);
@@ -399,7 +413,7 @@ template <typename P, bool WIDE> struct LHeap {
 		} else {
 			__hip_atomic_store(&chunk_ptr(c)[0].z, xhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (xhead == NONE32) xtail = c;
-			xhead = c;
+			xhead = c; xcnt++;
 		}
 		return c;
 	}
@@ -413,7 +427,8 @@ template <typename P, bool WIDE> struct LHeap {
 			const unsigned long long want = (((old >> 32) + 1) << 32) | xhead;
 			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
 		}
-		xhead = xtail = NONE32;
+		__hip_atomic_fetch_add(nfree, xcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		xhead = xtail = NONE32; xcnt = 0;
 	}
 	/* makes room for k (<= 63) more entries on a bucket whose state is st; returns the state to push from */
 	__device__ __forceinline__ uint32_t reserve(uint32_t st, int k, bool &ovf) {
@@ -431,7 +446,7 @@ template <typename P, bool WIDE> struct LHeap {
 		if (WIDE) {
 			p[fill * 2] = make_uint4((uint32_t)e.L, (uint32_t)((uint64_t)e.L >> 32), (uint32_t)e.U, (uint32_t)((uint64_t)e.U >> 32));
 			p[fill * 2 + 1] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-		} else p[fill] = make_uint4((uint32_t)e.L, (uint32_t)e.U, e.f, e.sa | (e.runsLo << 10));
+		} else p[fill] = make_uint4((uint32_t)e.L, (uint32_t)e.U, e.f, pack_w(e.L, e.U, e.sa, e.runsLo));
 	}
 	__device__ __forceinline__ void load_entry(uint32_t st, LEntry<P> &e) const {
 		const uint4 *p = chunk_ptr(st >> 6);
@@ -443,7 +458,8 @@ template <typename P, bool WIDE> struct LHeap {
 		} else {
 			const uint4 w = p[fill];
 			e.L = (P)w.x; e.U = (P)w.y; e.f = w.z; e.sa = w.w & 0x3FFu;
-			e.runsLo = 0xFFFF0000u | (w.w >> 10); e.runsHi = 0xFFFFFFFFu;
+			if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w.w >> 29) << 32); }
+			e.runsLo = 0xFFFF0000u | ((w.w >> 10) & 0xFFFFu); e.runsHi = 0xFFFFFFFFu;
 		}
 	}
 	/* pops the top entry of the cached bucket cb (the best non-empty one) */
@@ -482,7 +498,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	P *s_base = (P *)smem;
 	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
 	__shared__ unsigned long long s_blockfree;
-	if (threadIdx.x == 0) s_blockfree = ~0ull;
+	__shared__ unsigned int s_active, s_nfree; /* reads in flight in this block; chunks on its recycle stack */
+	if (threadIdx.x == 0) { s_blockfree = ~0ull; s_active = 0; s_nfree = 0; }
 	load_base<P>(s_base, ix);
 	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
@@ -495,8 +512,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	constexpr int ESZ = WIDE ? 2 : 1; /* uint4 per heap entry */
 
 	LHeap<P, WIDE> h;
-	h.pool = sc.pool; h.pool_bump = sc.pool_bump; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
-	h.phead = h.ptail = h.xhead = h.xtail = NONE32; h.pcnt = 0; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
+	const uint32_t region = blockIdx.x % sc.n_regions;
+	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
+	h.phead = h.ptail = h.xhead = h.xtail = NONE32; h.pcnt = 0; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
 	for (int k = 0; k < nb; k++) h.bstate[(size_t)k * h.nslots] = NONE32;
 
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	const uint8_t *seq = b.reads;
 	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed only when the read completes */
-	unsigned long long n_iter = 0;
+	unsigned long long n_iter = 0, w_iter = 0;
 	uint32_t r_iter = 0;
 #ifdef BWB_STAMPS
 	unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -522,10 +540,25 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 
 	for (;;) {
 		STAMP(7);
-		if (!active && !done) {
+		bool admit = !active && !done;
+		if (admit) {
+			/* admission: what a read will need is not known in advance, and a read that finds the pool empty is given up and
+			 * re-run, which costs far more than waiting.  So once three quarters of the region are taken a block starts a
+			 * read only against memory it can see: its recycle stack plus its share of what is left of the region. */
+			const uint32_t used = __hip_atomic_load(h.pool_bump, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (used >= h.pool_cap - (h.pool_cap >> 2)) {
+				const uint32_t left = used < h.pool_cap ? h.pool_cap - used : 0u;
+				const uint32_t blocks_in_region = (gridDim.x + sc.n_regions - 1) / sc.n_regions;
+				const uint32_t avail = s_nfree + left / blocks_in_region;
+				const uint32_t mine = __popcll(__ballot(true) & ((1ull << (threadIdx.x & 63u)) - 1ull));
+				admit = avail >= ADMIT_CHUNKS * (mine + 1) || s_active + mine < 4;
+			}
+		}
+		if (admit) {
 			rid = grab_read(b);
 			if (rid == NONE32) done = true;
 			else {
+				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				r_vis_s = r_vis_a = r_pop = r_push = 0; r_iter = 0;
 				len = b.lens[rid];
 				seq = b.reads + (size_t)rid * b.stride;
@@ -544,15 +577,17 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				}
 				best_score = kp.num_buckets; /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
 				max_diff = kp.max_diff; num_best = 0;
-				if (ovf0) { b.status[rid] = ST_SCRATCH_OVF; out.n[rid] = 0; h.release_excess(); active = false; }
+				if (ovf0) { b.status[rid] = ST_SCRATCH_OVF; out.n[rid] = 0; h.release_excess(); active = false; __hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 			}
 		}
 		if (__all(done)) break;
+		if (!__any(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
 
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false;
 		P iL = 0, iU = 0;
 		int widx = 0;
 		if (active) { n_iter++; r_iter++; }
+		w_iter++;
 
 		/* add_alignment (align.c:271-298) into the lane's private hit list */
 		auto add_aln = [&](P L, P U, int score, int alen) {
@@ -725,7 +760,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 							if (WIDE) {
 								p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
 								p[1] = make_uint4(f, sa, (uint32_t)runs, (uint32_t)(runs >> 32));
-							} else p[0] = make_uint4((uint32_t)L, (uint32_t)U, f, sa | ((uint32_t)runs << 10));
+							} else p[0] = make_uint4((uint32_t)L, (uint32_t)U, f, LHeap<P, WIDE>::pack_w(L, U, sa, (uint32_t)runs));
 							p += ESZ;
 						};
 						bool top_ok = false; /* does h.top mirror the last entry stored on bucket sc0? */
@@ -847,6 +882,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			if (!ovf && !outovf && !heavy) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
 			/* leave every bucket state empty for the next read and give its chunks back */
 			h.release_excess();
+			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			h.bstate[(size_t)h.cb * h.nslots] = NONE32;
 			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[(size_t)k * h.nslots] = NONE32; h.unmark(k); }
 			active = false;
@@ -859,6 +895,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	if (n_aln_tot) atomicAdd(&stats[STAT_ALNS], n_aln_tot);
 	atomicAdd(&stats[STAT_N], n_iter);        /* debug: total loop iterations */
 	atomicMax(&stats[STAT_N_MAX], n_iter);    /* debug: longest lane */
+	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[16], w_iter); /* debug: wave iterations */
 #ifdef BWB_STAMPS
 	if (n_iter) for (int k = 0; k < 8; k++) atomicAdd(&stats[8 + k], seg[k]);
 #endif
