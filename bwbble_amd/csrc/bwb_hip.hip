@@ -63,7 +63,7 @@ struct bwb_hip_ctx {
 	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes, POOL_REGIONS equal regions */
 	size_t pool_bytes = 0;
 	unsigned int *d_pool_bump = nullptr;
-	uint32_t keep = 64;
+	uint32_t keep = 256;                /* chunks of a lane's private run (BWB_KEEP) */
 	uint32_t *d_dbg_iters = nullptr;    /* BWB_DEBUG_ITERS: per-read iteration counts */
 	int bpc_search = 2, bpc_calcd = 2;
 	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
@@ -109,7 +109,7 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	HIPCHK(hipMalloc(&c->d_buckets, nblk * 128));
 	HIPCHK(hipMalloc(&c->d_counter, 64));
 	HIPCHK(hipMalloc(&c->d_count, 64));
-	HIPCHK(hipMalloc(&c->d_stats, sizeof(unsigned long long) * 24));
+	HIPCHK(hipMalloc(&c->d_stats, sizeof(unsigned long long) * 40));
 
 	/* superblock base table */
 	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
@@ -376,6 +376,10 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	s.sc.n_regions = std::max<uint32_t>(1, std::min<uint32_t>(POOL_REGIONS, grid / 8));
 	s.sc.region_u4 = c->pool_bytes / s.sc.n_regions / 4096 * 256;
 	s.sc.pool_cap = (uint32_t)std::min<size_t>(s.sc.region_u4 * 16 / (c->wide ? 2048 : 1024), (size_t)1 << 26);
+	{ /* private runs take at most half of a region */
+		const uint32_t lanes = (grid + s.sc.n_regions - 1) / s.sc.n_regions * LANE_BLOCK;
+		s.sc.keep = std::min<uint32_t>(c->keep, s.sc.pool_cap / 2 / lanes);
+	}
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	if (c->pos32 && !c->wide)
 		hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
@@ -395,8 +399,9 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 		unsigned int bump[POOL_REGIONS * 16], used_max = 0;
 		unsigned long long used = 0;
 		hipMemcpy(bump, c->d_pool_bump, sizeof(bump), hipMemcpyDeviceToHost);
-		for (uint32_t r = 0; r < s.sc.n_regions; r++) { used += std::min(bump[r * 16], s.sc.pool_cap); used_max = std::max(used_max, bump[r * 16]); }
-		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, budget %u, lane stride %u, %.3f ms, pool chunks used %llu of %d x %u (fullest region asked for %u)\n", k, n_work, grid, iter_budget, lane_stride, ms, used, (int)s.sc.n_regions, s.sc.pool_cap, used_max);
+		const uint32_t priv = (grid + s.sc.n_regions - 1) / s.sc.n_regions * LANE_BLOCK * s.sc.keep;
+		for (uint32_t r = 0; r < s.sc.n_regions; r++) { used += std::min(priv + bump[r * 16], s.sc.pool_cap); used_max = std::max(used_max, priv + bump[r * 16]); }
+		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, budget %u, lane stride %u, %.3f ms, pool chunks used %llu of %d x %u (fullest region asked for %u; %u private per lane)\n", k, n_work, grid, iter_budget, lane_stride, ms, used, (int)s.sc.n_regions, s.sc.pool_cap, used_max, s.sc.keep);
 	}
 	return BWB_OK;
 }
@@ -429,7 +434,7 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	if (!c || !c->uploaded) return fail(BWB_E_STATE, "batch_run: no batch uploaded");
 	HIPCHK(hipSetDevice(c->device));
 	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 24, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 40, c->stream));
 	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
 	if (c->n_reads == 0) { c->ran = true; return BWB_OK; }
 	HIPCHK(hipMemsetAsync(c->d_n, 0, (size_t)c->n_reads * 4, c->stream));
@@ -477,13 +482,19 @@ extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
 	HIPCHK(hipEventElapsedTime(&ms, t0, t1));
 	c->stats.ms_total = ms;
 	hipEventDestroy(t0); hipEventDestroy(t1);
-	unsigned long long st[24];
+	unsigned long long st[40];
 	HIPCHK(hipMemcpy(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
 	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA]; c->stats.visits_calc_d = st[STAT_VIS_CALCD];
 	c->stats.heap_pops = st[STAT_POPS]; c->stats.heap_pushes = st[STAT_PUSHES]; c->stats.n_alignments = st[STAT_ALNS];
 	if (getenv("BWB_DEBUG")) {
 		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu, wave iterations %llu (%.1f of 64 lanes busy)\n", st[STAT_N], st[STAT_N_MAX], st[16], st[16] ? (double)st[STAT_N] / (double)st[16] : 0.0);
-		fprintf(stderr, "[bwb] stamps (cycles): top %llu | A(pop) %llu | B(issue) %llu | C(rank) %llu | D(act) %llu | E(exact) %llu | F(finish..) %llu\n", st[8+0], st[8+1], st[8+2], st[8+3], st[8+4], st[8+5], st[8+7]);
+		if (st[24 + 3]) {
+			double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[24 + k];
+			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E(exact)", "-", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "-", "-" };
+			fprintf(stderr, "[bwb] stamps (%% of lane cycles):");
+			for (int k = 0; k < 16; k++) if (st[24 + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[24 + k] / tot);
+			fprintf(stderr, "\n");
+		}
 	}
 	c->ran = true;
 	return BWB_OK;
@@ -544,7 +555,7 @@ extern "C" int bwb_hip_calc_d(bwb_hip_ctx *c, int32_t *out_D, int32_t *out_Dseed
 	HIPCHK(hipMemset(dD, 0, (nD ? nD : 1) * 4));
 	HIPCHK(hipMemset(dS, 0, (nS ? nS : 1) * 4));
 	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 24, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 40, c->stream));
 	int rc = c->n_reads ? run_calc_d(c, dD, dS) : BWB_OK;
 	if (!rc) {
 		hipMemcpy(out_D, dD, nD * 4, hipMemcpyDeviceToHost);

@@ -16,9 +16,9 @@
  * VALU-bound at ~4 us per iteration).  Lanes pull reads from a global cursor (work stealing).
  *
  * Per-lane memory (global, private to the lane while it owns a read):
- *   heap    : chains of 64-slot chunks from a shared pool (atomic bump allocation); a lane keeps its first `keep`
- *             chunks, what a read takes beyond them goes to the block's lock-free stack of recycled chunks when the
- *             read ends.  slot 0 = header.
+ *   heap    : chains of 64-slot chunks; a lane owns a private run of `keep` chunks, what a read takes beyond them comes
+ *             from the block's lock-free stack of recycled chunks or the shared pool (atomic bump allocation) and goes
+ *             to that stack when the read ends.  slot 0 = header.
  *   bstate  : [bucket][slot] u32 = chunk<<6 | fill; the bucket being popped is cached in registers.
  *   lists   : two SA-interval lists (cur/next) with the open tail in registers.
  *   hits    : the read's alignments (needed for the gapped-duplicate check, align.c:273-280).
@@ -352,8 +352,9 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t pool_cap;
 	uint32_t *bstate;      /* this lane's column: bstate[s * nslots] */
 	uint32_t nslots;
-	uint32_t fhead;        /* chunks emptied by pops during this read */
-	uint32_t phead, ptail, ocur, pcnt, keep; /* private chain and the walk over it */
+	uint32_t fhead, fnext; /* chunks emptied by pops during this read (LIFO through header .x) and the link of its head */
+	uint32_t pbase, pused, keep; /* the lane's private run of `keep` consecutive chunks and how many of them this read has taken */
+	uint32_t pshared;            /* first chunk of the region's shared part (after every lane's private run) */
 	uint32_t xhead, xtail;       /* chunks the current read took beyond the private chain */
 	Lds<unsigned long long> blockfree; /* head of this block's stack of recycled chunks (LDS): version<<32 | chunk */
 	Lds<unsigned int> nfree;     /* chunks on that stack */
@@ -373,7 +374,7 @@ template <typename P, bool WIDE> struct LHeap {
 		return w;
 	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { fhead = NONE32; ocur = phead; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
+	__device__ __forceinline__ void reset() { fhead = fnext = NONE32; pused = 0; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
 	__device__ __forceinline__ void mark(int s) { if (s < 64) neLo |= 1ull << s; else neHi |= 1ull << (s - 64); }
 	__device__ __forceinline__ void unmark(int s) { if (s < 64) neLo &= ~(1ull << s); else neHi &= ~(1ull << (s - 64)); }
 	__device__ __forceinline__ int best(int nb) const {
@@ -385,15 +386,20 @@ template <typename P, bool WIDE> struct LHeap {
 		cb = s; cst = bstate[(size_t)s * nslots];
 		top_valid = false;
 	}
-	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private chain (the first `keep`
-	 * chunks it ever took, header .z, rewound at every read so that an ordinary read allocates without any atomic); the
-	 * block's stack of chunks recycled by finished reads (lock-free: versioned head, so a pop cannot be fooled by a chunk
-	 * that left and came back); the pool.  What a read takes beyond the private chain is threaded on its excess chain
-	 * and goes back to the block stack in one push when the read ends, so the pool holds what the reads in flight need,
-	 * not the worst case every lane has ever seen. */
+	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private run of `keep` consecutive
+	 * chunks at the start of its region (a counter: an ordinary read allocates without touching memory); the block's stack
+	 * of chunks recycled by finished reads (lock-free: versioned head, so a pop cannot be fooled by a chunk that left and
+	 * came back); the shared part of the region (atomic bump).  What a read takes beyond its private run is threaded on its
+	 * excess chain and goes back to the block stack in one push when the read ends, so the pool holds what the reads in
+	 * flight need, not the worst case every lane has ever seen. */
 	__device__ __forceinline__ uint32_t alloc(bool &ovf) {
-		if (fhead != NONE32) { const uint32_t c = fhead; fhead = chunk_ptr(c)[0].x; return c; }
-		if (ocur != NONE32) { const uint32_t c = ocur; ocur = chunk_ptr(c)[0].z; return c; }
+		if (fhead != NONE32) { /* the link of the new head is fetched now and needed at the next allocation at the earliest */
+			const uint32_t c = fhead;
+			fhead = fnext;
+			fnext = fhead != NONE32 ? chunk_ptr(fhead)[0].x : NONE32;
+			return c;
+		}
+		if (pused < keep) return pbase + pused++;
 		uint32_t c = NONE32;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		while ((uint32_t)old != NONE32) {
@@ -403,18 +409,12 @@ template <typename P, bool WIDE> struct LHeap {
 			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { c = top; __hip_atomic_fetch_add(nfree, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
 		}
 		if (c == NONE32) {
-			c = atomicAdd(pool_bump, 1u);
+			c = pshared + atomicAdd(pool_bump, 1u);
 			if (c >= pool_cap) { ovf = true; return 0; }
 		}
-		if (pcnt < keep) {
-			chunk_ptr(c)[0].z = NONE32;
-			if (ptail != NONE32) chunk_ptr(ptail)[0].z = c; else phead = c;
-			ptail = c; pcnt++;
-		} else {
-			__hip_atomic_store(&chunk_ptr(c)[0].z, xhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (xhead == NONE32) xtail = c;
-			xhead = c; xcnt++;
-		}
+		__hip_atomic_store(&chunk_ptr(c)[0].z, xhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (xhead == NONE32) xtail = c;
+		xhead = c; xcnt++;
 		return c;
 	}
 	/* end of a read: hand the chunks it took beyond the private chain to the block */
@@ -468,7 +468,7 @@ template <typename P, bool WIDE> struct LHeap {
 		if ((cst & 63u) == 1u) {
 			uint4 *p = chunk_ptr(cst >> 6);
 			const uint32_t pv = p[0].y;
-			p[0].x = fhead; fhead = cst >> 6; /* chunk goes to the private free list */
+			p[0].x = fhead; fnext = fhead; fhead = cst >> 6; /* chunk goes to the private free list */
 			cst = pv;
 			if (pv == NONE32) unmark(cb);
 			top_valid = false;
@@ -513,8 +513,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 
 	LHeap<P, WIDE> h;
 	const uint32_t region = blockIdx.x % sc.n_regions;
+	h.pbase = ((blockIdx.x / sc.n_regions) * LANE_BLOCK + threadIdx.x) * sc.keep;
+	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
-	h.phead = h.ptail = h.xhead = h.xtail = NONE32; h.pcnt = 0; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
+	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
 	for (int k = 0; k < nb; k++) h.bstate[(size_t)k * h.nslots] = NONE32;
 
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	unsigned long long n_iter = 0, w_iter = 0;
 	uint32_t r_iter = 0;
 #ifdef BWB_STAMPS
-	unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
+	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
 #endif
 
 	for (;;) {
@@ -543,10 +545,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 		bool admit = !active && !done;
 		if (admit) {
 			/* admission: what a read will need is not known in advance, and a read that finds the pool empty is given up and
-			 * re-run, which costs far more than waiting.  So once three quarters of the region are taken a block starts a
+			 * re-run, which costs far more than waiting.  So once three quarters of the region's shared part are taken a block starts a
 			 * read only against memory it can see: its recycle stack plus its share of what is left of the region. */
-			const uint32_t used = __hip_atomic_load(h.pool_bump, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (used >= h.pool_cap - (h.pool_cap >> 2)) {
+			const uint32_t used = h.pshared + __hip_atomic_load(h.pool_bump, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (used >= h.pool_cap - ((h.pool_cap - h.pshared) >> 2)) {
 				const uint32_t left = used < h.pool_cap ? h.pool_cap - used : 0u;
 				const uint32_t blocks_in_region = (gridDim.x + sc.n_regions - 1) / sc.n_regions;
 				const uint32_t avail = s_nfree + left / blocks_in_region;
@@ -699,6 +701,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 					mode = LMODE_EXACT;
 					exact_step = true;
 				} else {
+					STAMP(8);
 					/* ---- expansion :377-504 ---- */
 					r_vis_a += nvis;
 					bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
@@ -734,9 +737,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 					const int k0 = n0 + (tX == 0 ? nX : 0) + (tG == 0 ? nG : 0);
 					const int k1 = (tX == 1 ? nX : 0) + (tG == 1 ? nG : 0);
 					const int k2 = tG == 2 ? nG : 0;
+					STAMP(9);
 					uint32_t st0 = h.reserve(h.cst, k0, ovf);
 					uint32_t st1 = h.reserve(stX, k1, ovf);
 					uint32_t st2 = h.reserve(stG, k2, ovf);
+					STAMP(10);
 					if (!ovf) {
 						/* child entry templates */
 						const uint32_t alen1 = (uint32_t)((e_alen + 1) & 255);
@@ -764,6 +769,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 							p += ESZ;
 						};
 						bool top_ok = false; /* does h.top mirror the last entry stored on bucket sc0? */
+						STAMP(11);
 						{ /* gap pushes: insertion (keeps the interval), then deletions in code order */
 							uint4 *pg = tG == 0 ? p0 : (tG == 1 ? p1 : p2);
 							uint32_t gm = gapm;
@@ -776,6 +782,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 							}
 							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
 						}
+						STAMP(12);
 						const uint32_t sm = (uint32_t)STATE_M | (alen1 << 2);
 						if (kp.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
 							uint4 *px = tX == 1 ? p1 : p0;
@@ -802,6 +809,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 								emit(p0, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
 							}
 						}
+						STAMP(13);
 						h.num_entries += nG + nX + n0;
 						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; }
 						if (k1 > 0) { h.bstate[(size_t)scX * h.nslots] = st1 + (uint32_t)k1; h.mark(scX); }
@@ -897,6 +905,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	atomicMax(&stats[STAT_N_MAX], n_iter);    /* debug: longest lane */
 	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[16], w_iter); /* debug: wave iterations */
 #ifdef BWB_STAMPS
-	if (n_iter) for (int k = 0; k < 8; k++) atomicAdd(&stats[8 + k], seg[k]);
+	if (n_iter) for (int k = 0; k < 16; k++) atomicAdd(&stats[24 + k], seg[k]);
 #endif
 }
