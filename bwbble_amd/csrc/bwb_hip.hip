@@ -242,7 +242,6 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
                                     uint32_t n_reads, uint32_t stride) {
 	if (!c || !p || (n_reads && (!reads_fwd || !lens)) || stride == 0) return fail(BWB_E_ARG, "batch_upload: bad argument");
-	if (!p->is_multiref) return fail(BWB_E_ARG, "single-genome mode (-S) is not supported by the GPU path yet");
 	if (p->use_precalc) return fail(BWB_E_ARG, "precalculated intervals (-P) are not supported by the GPU path yet");
 	if (p->max_gapo < 0 || p->max_gapo > 4) return fail(BWB_E_ARG, "max_gapo (-o) must be in [0,4] on the GPU path");
 	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
@@ -257,7 +256,7 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	HIPCHK(hipSetDevice(c->device));
 	c->p = *p;
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
-	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb };
+	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb, p->is_multiref ? 1 : 0 };
 	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
 	c->wide = p->max_gapo > 1;
 	/* per read: u16 {D[i-1], D[i-2]} for i = 0..maxlen+1, then u16 {Dseed[si-1], Dseed[si-2]}, then the N count */

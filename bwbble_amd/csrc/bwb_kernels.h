@@ -24,6 +24,7 @@ struct KParams {
 	int mm_score, gapo_score, gape_score;
 	int seed_length, max_diff_seed, max_best, no_indel_length;
 	int num_buckets;
+	int multiref;   /* 0: single-genome mode (-S): 4-letter children A,G,C,T in rows 1..4, 1-to-1 exact matching */
 };
 
 struct Batch {
@@ -55,6 +56,8 @@ template <typename P> struct Intv { P L, U; };
 
 /* io.h:29,109: read base c (A0 G1 C2 T3) is compatible with code j iff gray(c) & grayVal[j]; N(10) excluded
  * (nucl_bases_table io.h:102-106).  Bit j of the mask = code j is a member. */
+/* -S: child row j = 1..4 is base j-1 (A G C T), i.e. code nt4_gray[j-1] = 15, 3, 7, 1 (io.h:108, bwt.c:440-463) */
+__device__ __forceinline__ uint32_t single_mask_codes(int c) { return c == 0 ? 1u << 15 : (c == 1 ? 1u << 3 : (c == 2 ? 1u << 7 : 1u << 1)); }
 __device__ __forceinline__ uint32_t member_mask(int c) {
 	/* A {8,9,11,12,13,14,15}  G {2,3,4,5,11,12,13}  C {4,5,6,7,8,9,11}  T {1,2,5,6,9,13,14} */
 	return c == 0 ? 0xFB00u : (c == 1 ? 0x383Cu : (c == 2 ? 0x0BF0u : 0x6266u));

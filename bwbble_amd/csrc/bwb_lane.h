@@ -275,7 +275,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			lane_issue<P>(buckets, last_row, iU, rb);
 			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
 			uint32_t ne = lane_children<P>(ra, rb, s_base, false, kidL, kidU);
-			ne &= member_mask(c);
+			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
 			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
 				const int j = __ffs((int)ne) - 1;
 				ne &= ne - 1;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 						need_rank = true; iL = e.L; iU = e.U;
 						/* an entry with no difference left goes to the exact tail (exact counts); any other one is expanded
 						 * with O_alphabet (:345,382) */
-						alpha = (max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0;
+						alpha = kp.multiref && (max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0;
 					}
 				}
 			}
@@ -671,6 +671,15 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, alpha, iL, iU, kids, (int)(threadIdx.x & 63u));
 				for (int t = 0; t < 8; t++) rm &= rm - 1;
 			}
+		}
+		if (!kp.multiref && need_rank) {
+			/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with
+			 * alphabet_size 5): move codes 15, 3, 7, 1 to rows 1..4 */
+			const P a0 = kidL[15 * LANE_BLOCK], a1 = kidU[15 * LANE_BLOCK], g0 = kidL[3 * LANE_BLOCK], g1 = kidU[3 * LANE_BLOCK];
+			const P c0 = kidL[7 * LANE_BLOCK], c1 = kidU[7 * LANE_BLOCK], t0 = kidL[1 * LANE_BLOCK], t1 = kidU[1 * LANE_BLOCK];
+			kidL[1 * LANE_BLOCK] = a0; kidU[1 * LANE_BLOCK] = a1; kidL[2 * LANE_BLOCK] = g0; kidU[2 * LANE_BLOCK] = g1;
+			kidL[3 * LANE_BLOCK] = c0; kidU[3 * LANE_BLOCK] = c1; kidL[4 * LANE_BLOCK] = t0; kidU[4 * LANE_BLOCK] = t1;
+			ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
 		}
 		STAMP(3);
 
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 					const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
 					const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
 					const bool mm_ok = allow_diff && allow_mm;
-					const uint32_t mem = cr > 3 ? 0u : member_mask(cr);
+					const uint32_t mem = cr > 3 ? 0u : (kp.multiref ? member_mask(cr) : 2u << cr);
 					/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
 					const uint32_t gapm = (ins_ok ? 1u : 0u) | (del_ok ? ne : 0u);
 					const uint32_t mgrp = mm_ok ? ne : (ne & mem);
@@ -825,7 +834,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
 			else {
 				r_vis_s += nvis;
-				uint32_t nm = ne & member_mask(cr);
+				uint32_t nm = ne & (kp.multiref ? member_mask(cr) : 2u << cr);
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;

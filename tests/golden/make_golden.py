@@ -37,6 +37,10 @@ ALIGN_CONFIGS = {
     "n5": ["-n", "5"],
     "n4gap": ["-n", "4", "-o", "2", "-e", "3", "-l", "20", "-k", "1"],
     "n2pen": ["-n", "2", "-M", "4", "-O", "6", "-E", "4", "-o", "2"],  # mm_score == gape_score bucket collision
+    # single-genome mode (-S): 4-letter rank (O_actg_alphabet), 1-to-1 exact matching, children in A,G,C,T order
+    "s0": ["-S", "-n", "0"],
+    "s2": ["-S", "-n", "2"],
+    "s4gap": ["-S", "-n", "4", "-o", "2", "-e", "3", "-l", "20", "-k", "1"],
 }
 
 HARNESS = r"""
@@ -120,7 +124,7 @@ def main():
     os.remove(fa + ".ref")  # 400 kB of raw text, not needed by align/aln2sam
     for name, flags in ALIGN_CONFIGS.items():
         run([REF_BIN, "align"] + flags + [fa, fq, os.path.join(HERE, f"toy_{name}.aln")])
-    for name in ("n0", "n3", "n4gap"):
+    for name in ("n0", "n3", "n4gap", "s2"):
         run([REF_BIN, "align"] + ALIGN_CONFIGS[name] + [fa, fq2, os.path.join(HERE, f"ragged_{name}.aln")])
     run([REF_BIN, "aln2sam", fa, fq, os.path.join(HERE, "toy_n3.aln"), os.path.join(HERE, "toy_n3.sam")])
     run([REF_BIN, "aln2sam", fa, fq2, os.path.join(HERE, "ragged_n4gap.aln"), os.path.join(HERE, "ragged_n4gap.sam")])

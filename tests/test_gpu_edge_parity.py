@@ -46,7 +46,8 @@ def mid_ctx(mid, oracle):
 
 
 @pytest.mark.parametrize("flags", [["-n", "0"], ["-n", "2"], ["-n", "3"], ["-n", "4", "-o", "2", "-e", "4"],
-                                   ["-n", "3", "-l", "0"], ["-n", "3", "-k", "0", "-l", "40"]])
+                                   ["-n", "3", "-l", "0"], ["-n", "3", "-k", "0", "-l", "40"],
+                                   ["-S", "-n", "0"], ["-S", "-n", "3"], ["-S", "-n", "4", "-o", "2", "-e", "4"]])
 def test_mid_genome_matches_oracle(mid_ctx, oracle, flags):
     d, fa, ctx, idx = mid_ctx
     seqs, lens = synth_reads(fa, str(d / "a.fq"), 3000, 100, 5, sub=1.5, indel=2.0, npct=2.0)
@@ -109,7 +110,7 @@ def test_heavy_read_pass_is_exact(mid, oracle, monkeypatch):
 
 
 def test_force_64bit_positions(mid, oracle, monkeypatch):
-    """The 64-bit position / 32-byte entry instantiation (used for > 4 G-row indexes) on a small index."""
+    """The 64-bit position instantiations (used for > 4 G-row indexes; 16-byte entries, 32-byte ones for -o > 1) on a small index."""
     d, fa = mid
     monkeypatch.setenv("BWB_FORCE_POS64", "1")
     ctx = bw.Context(fa + ".bwt")
@@ -117,4 +118,5 @@ def test_force_64bit_positions(mid, oracle, monkeypatch):
     seqs, lens = synth_reads(fa, str(d / "w.fq"), 2000, 100, 12, sub=1.5, indel=2.0)
     check(ctx, oracle, idx, ["-n", "3"], seqs, lens)
     check(ctx, oracle, idx, ["-n", "3", "-o", "2"], seqs, lens)
+    check(ctx, oracle, idx, ["-S", "-n", "2"], seqs, lens)
     ctx.close()
