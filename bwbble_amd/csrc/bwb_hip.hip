@@ -242,7 +242,6 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
                                     uint32_t n_reads, uint32_t stride) {
 	if (!c || !p || (n_reads && (!reads_fwd || !lens)) || stride == 0) return fail(BWB_E_ARG, "batch_upload: bad argument");
-	if (p->use_precalc) return fail(BWB_E_ARG, "precalculated intervals (-P) are not supported by the GPU path yet");
 	if (p->max_gapo < 0 || p->max_gapo > 4) return fail(BWB_E_ARG, "max_gapo (-o) must be in [0,4] on the GPU path");
 	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
 	if (p->seed_length < 0 || p->seed_length > 255) return fail(BWB_E_ARG, "seed_length must be in [0,255]");
@@ -252,11 +251,14 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	if (p->max_entries < 1) return fail(BWB_E_ARG, "max_entries must be positive");
 	uint32_t maxlen = 0;
 	for (uint32_t i = 0; i < n_reads; i++) maxlen = std::max<uint32_t>(maxlen, lens[i]);
+	if (p->use_precalc)
+		for (uint32_t i = 0; i < n_reads; i++)
+			if (lens[i] < PRECALC_LEN) return fail(BWB_E_ARG, "-P needs reads of at least 12 bases (read2index, align.c:174-186, reads before the buffer otherwise)");
 	if (maxlen > 255 || maxlen > stride) return fail(BWB_E_ARG, "reads longer than 255 bases (or than stride) are not supported (aln_entry_t.i is 8-bit, align.h:104)");
 	HIPCHK(hipSetDevice(c->device));
 	c->p = *p;
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
-	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb, p->is_multiref ? 1 : 0 };
+	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb, p->use_precalc ? 1 : 0, p->is_multiref ? 1 : 0 };
 	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
 	c->wide = p->max_gapo > 1;
 	/* per read: u16 {D[i-1], D[i-2]} for i = 0..maxlen+1, then u16 {Dseed[si-1], Dseed[si-2]}, then the N count */

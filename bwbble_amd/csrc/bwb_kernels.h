@@ -24,6 +24,7 @@ struct KParams {
 	int mm_score, gapo_score, gape_score;
 	int seed_length, max_diff_seed, max_best, no_indel_length;
 	int num_buckets;
+	int use_precalc; /* -P: the heap starts from the exact matches of the last 12 bases of rc (inexact_match.c:269-279) */
 	int multiref;   /* 0: single-genome mode (-S): 4-letter children A,G,C,T in rows 1..4, 1-to-1 exact matching */
 };
 

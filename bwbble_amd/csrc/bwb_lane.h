@@ -35,6 +35,7 @@
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define CHUNK_SLOTS 64          /* slot 0 is the header: 63 entries per chunk */
 #define POOL_REGIONS 8
+#define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 
 struct LaneScratch {
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 						Ws[i] = (uint16_t)((si >= 1 ? 0x80u : 0u) | (si >= 2 ? 0x8000u : 0u));
 					}
 				}
+				if (active && kp.use_precalc) /* -P: a read with an N in the last 12 bases of rc is dropped before calculate_d (inexact_match.c:129-136) */
+					for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) active = false;
 				if (!active) { b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = 0; b.status[rid] = ST_OK; }
 			}
 		}
@@ -524,7 +527,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	uint32_t rid = 0;
 	int len = 0, mode = LMODE_POP;
 	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
-	int r = 0, s = 0, curT = 0, cursel = 0;                 /* exact-tail state */
+	int r = 0, s = 0, curT = 0, cursel = 0, r_stop = 0;     /* exact-tail state; it ends after rc[r_stop] */
+	bool seeding = false;                                   /* -P: the exact steps under way build the read's first heap entries */
 	P cL = 0, cU = 0;
 	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
@@ -570,7 +574,22 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
 				n_alns = 0; mode = LMODE_POP; active = true;
 				bool ovf0 = false;
-				if (!(cntN > kp.max_diff || len == 0)) { /* inexact_match.c:260-266 */
+				bool skip = cntN > kp.max_diff || len == 0; /* inexact_match.c:260-266 */
+				seeding = false; r_stop = 0;
+				if (kp.use_precalc && !skip) {
+					/* -P.  A read with an N in the last 12 bases of rc (= the first 12 of seq) gets an empty record
+					 * (inexact_match.c:129-136).  Otherwise the heap starts from the precalculated list of that 12-mer
+					 * (:269-279); the list is exact_match() of the 12-mer (align.c:212-216), a pure function of it, so the
+					 * 12 exact steps are run here instead of reading the 16.7 M-list .pre table. */
+					for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) skip = true;
+					if (!skip) {
+						seeding = true; r_stop = len - PRECALC_LEN;
+						cL = 0; cU = last_row; curT = 1; cursel = 0; s = 0; r = len - 1;
+						nx.buf = lbase + lcap; nx.T = 0;
+						mode = LMODE_EXACT;
+					}
+				}
+				if (!skip && !seeding) {
 					/* heap_push(root) inexact_match.c:281 */
 					LEntry<P> root; root.L = 0; root.U = last_row; root.f = (uint32_t)len; root.sa = 0; root.runsLo = root.runsHi = ~0u;
 					h.cst = h.reserve(NONE32, 1, ovf0);
@@ -833,7 +852,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			bool exact_done = false;
 			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
 			else {
-				r_vis_s += nvis;
+				if (!seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
 				uint32_t nm = ne & (kp.multiref ? member_mask(cr) : 2u << cr);
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
@@ -845,10 +864,26 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 					cursel ^= 1; curT = nx.T; cL = nx.tL; cU = nx.tU;
 					nx.buf = lbase + (cursel ^ 1) * lcap; nx.T = 0; s = 0;
 					if (curT == 0) exact_done = true; /* :114 */
-					else { r--; if (r < 0) exact_done = true; }
+					else { r--; if (r < r_stop) exact_done = true; }
 				}
 			}
-			if (exact_done && !ovf) {
+			if (exact_done && !ovf && seeding) {
+				/* :269-279: one entry per interval, i = readLen - 12, a 12-long all-M path; no interval: no alignment */
+				mode = LMODE_POP; seeding = false; r_stop = 0;
+				if (curT == 0) finish = true;
+				else {
+					LEntry<P> ent; ent.f = (uint32_t)(len - PRECALC_LEN); ent.sa = (uint32_t)STATE_M | ((uint32_t)PRECALC_LEN << 2); ent.runsLo = ent.runsHi = ~0u;
+					ent.L = ent.U = 0;
+					uint32_t st = h.cst; /* bucket 0 of the empty heap */
+					for (int k = 0; k < curT && !ovf; k++) {
+						if (k == curT - 1) { ent.L = cL; ent.U = cU; }
+						else { const Intv<P> v = (lbase + cursel * lcap)[k]; ent.L = v.L; ent.U = v.U; }
+						st = h.reserve(st, 1, ovf);
+						if (!ovf) { st++; h.store_entry(st, ent); }
+					}
+					if (!ovf) { h.cst = st; h.mark(0); h.num_entries = curT; h.top = ent; h.top_valid = true; r_push += (uint32_t)curT; }
+				}
+			} else if (exact_done && !ovf) {
 				mode = LMODE_POP;
 				if (curT != 0) { /* matches found :347-371 */
 					const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;

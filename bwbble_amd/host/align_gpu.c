@@ -134,7 +134,6 @@ int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_
 	t = wall();
 	reads_t *reads = fastq2reads(readsFname);
 	printf("Total read loading time: %.2f sec\n", wall() - t);
-	if (params->use_precalc) bwb_die("align: pre-calculated intervals (-P) are not supported by the GPU path yet");
 	t = wall();
 	align_reads_inexact_gpu(BWT, reads, NULL, params, alnsFname, n_gpus);   /* the seam: align.c:72-76 */
 	printf("Total read alignment time: %.2f sec\n", wall() - t);

@@ -232,7 +232,12 @@ static void calc_d(const bwb_or_index *x, const uint8_t *read, int len, bwb_or_d
 }
 
 /* single-genome branch inexact_match.c:176-206 (codes A=15,G=3,C=7,T=1) */
-static void calc_d_single(const bwb_or_index *x, const uint8_t *read, int len, bwb_or_dlb *D) {
+/* rank-block visits of one (L-1, U) position pair, SURVEY 8(d): 0 for the special-cased positions */
+static void count_pair(const bwb_or_index *x, uint64_t iL, uint64_t iU, uint64_t *ctr) {
+	if (iL != (uint64_t)-1 && iL != x->length - 1) (*ctr)++;
+	if (iU != (uint64_t)-1 && iU != x->length - 1) (*ctr)++;
+}
+static void calc_d_single(const bwb_or_index *x, const uint8_t *read, int len, bwb_or_dlb *D, bwb_or_stats *st) {
 	static const int nt4_gray[5] = { 15, 3, 7, 1, 10 };
 	int z = 0;
 	uint64_t L = 0, U = x->length - 1;
@@ -240,6 +245,7 @@ static void calc_d_single(const bwb_or_index *x, const uint8_t *read, int len, b
 		int c = nt4_gray[read[i]];
 		if (c == 10) { L = 0; U = x->length - 1; z++; }
 		else {
+			if (st) count_pair(x, L - 1, U, &st->visits_single);
 			uint64_t oL = bwb_or_O(x, c, L - 1), oU = (L - 1 == U) ? oL : bwb_or_O(x, c, U);
 			L = x->C[c] + oL + 1; U = x->C[c] + oU;
 			if (L > U) { L = 0; U = x->length - 1; z++; }
@@ -252,7 +258,7 @@ static void calc_d_single(const bwb_or_index *x, const uint8_t *read, int len, b
 }
 
 void bwb_or_calculate_d(const bwb_or_index *x, const uint8_t *seq, int len, bwb_or_dlb *D, const bwb_or_params *p, bwb_or_stats *st) {
-	if (!p->is_multiref) { calc_d_single(x, seq, len, D); return; }
+	if (!p->is_multiref) { calc_d_single(x, seq, len, D, NULL); return; }
 	ilist_t a = { 0 }, b = { 0 };
 	calc_d(x, seq, len, D, &a, &b, st);
 	free(a.v); free(b.v);
@@ -350,7 +356,7 @@ static int exact_bounded(bwb_or_aligner *a, const uint8_t *read, uint64_t l, uin
 	return cur->size != 0;
 }
 /* exact_match_1to1_bounded exact_match.c:196-222 as used by exact_match.c:69-77 (-S) */
-static int exact_bounded_single(bwb_or_aligner *a, const uint8_t *read, uint64_t l, uint64_t u, int i) {
+static int exact_bounded_single(bwb_or_aligner *a, const uint8_t *read, uint64_t l, uint64_t u, int i, bwb_or_stats *st) {
 	static const int nt4_gray[5] = { 15, 3, 7, 1, 10 };
 	const bwb_or_index *x = a->x;
 	a->la.size = 0;
@@ -358,6 +364,7 @@ static int exact_bounded_single(bwb_or_aligner *a, const uint8_t *read, uint64_t
 	for (int r = i; r >= 0; r--) {
 		if (read[r] > 3) return 0;
 		int c = nt4_gray[read[r]];
+		if (st) count_pair(x, L - 1, U, &st->visits_single);
 		uint64_t oL = bwb_or_O(x, c, L - 1), oU = bwb_or_O(x, c, U);
 		L = x->C[c] + oL + 1; U = x->C[c] + oU;
 		if (L > U) return 0;
@@ -374,7 +381,8 @@ static void O_actg(const bwb_or_index *x, uint64_t i, uint64_t occ[16], int inc)
 	for (int j = 1; j <= 4; j++) occ[j] = x->C[code[j]] + bwb_or_O(x, code[j], i) + inc;
 }
 
-/* inexact_match, inexact_match.c:256-506 (precalc == NULL) */
+#define BWB_OR_PRECALC_LEN 12 /* PRECALC_INTERVAL_LENGTH align.h:31 */
+/* inexact_match, inexact_match.c:256-506 */
 static void inexact_match(bwb_or_aligner *a, const uint8_t *read, int readLen, bwb_or_stats *st) {
 	const bwb_or_index *x = a->x;
 	const bwb_or_params *p = &a->p;
@@ -388,8 +396,24 @@ static void inexact_match(bwb_or_aligner *a, const uint8_t *read, int readLen, b
 	if (countN > p->max_diff) return;
 
 	heap_reset(heap);
-	heap_push(heap, readLen, 0, x->length - 1, 0, 0, 0, 0, 0, 0, NULL, 0, p);
-	if (st) st->heap_pushes++;
+	if (p->use_precalc) {
+		/* inexact_match.c:269-279: one entry per interval of the 12-mer's precalculated list, at i = readLen - 12 with a
+		 * 12-long all-M path.  The table entry is exact_match() of the 12-mer (align.c:212-216 -> exact_match.c:57-59),
+		 * a pure function of it, so it is computed here instead of being read from the .pre file; those rank calls are
+		 * not reference work and are not counted. */
+		const uint8_t *mer = read + readLen - BWB_OR_PRECALC_LEN;
+		int found = p->is_multiref ? exact_bounded(a, mer, 0, x->length - 1, BWB_OR_PRECALC_LEN - 1, NULL)
+		                           : exact_bounded_single(a, mer, 0, x->length - 1, BWB_OR_PRECALC_LEN - 1, NULL);
+		if (!found) return; /* :277 */
+		uint8_t zeros[BWB_OR_PRECALC_LEN] = { 0 };
+		for (int k = 0; k < a->la.size; k++) {
+			heap_push(heap, readLen - BWB_OR_PRECALC_LEN, a->la.v[k].L, a->la.v[k].U, 0, 0, 0, 0, 0, BWB_OR_PRECALC_LEN - 1, zeros, 1, p);
+			if (st) st->heap_pushes++;
+		}
+	} else {
+		heap_push(heap, readLen, 0, x->length - 1, 0, 0, 0, 0, 0, 0, NULL, 0, p);
+		if (st) st->heap_pushes++;
+	}
 
 	int best_score = aln_score(p->max_diff + 1, p->max_gapo + 1, p->max_gape + 1, p);
 	int best_diff = p->max_diff + 1;
@@ -426,7 +450,7 @@ static void inexact_match(bwb_or_aligner *a, const uint8_t *read, int readLen, b
 			continue;
 		} else if (diff_left == 0) {
 			int found = p->is_multiref ? exact_bounded(a, read, e->L, e->U, e->i - 1, st)
-			                           : exact_bounded_single(a, read, e->L, e->U, e->i - 1);
+			                           : exact_bounded_single(a, read, e->L, e->U, e->i - 1, st);
 			if (found) {
 				ilist_t *sa = &a->la;
 				int score = aln_score(e->num_mm, e->num_gapo, e->num_gape, p);
@@ -461,6 +485,7 @@ static void inexact_match(bwb_or_aligner *a, const uint8_t *read, int readLen, b
 		} else {
 			O_actg(x, e->L - 1, L, 1);
 			O_actg(x, e->U, U, 0);
+			if (st) count_pair(x, e->L - 1, e->U, &st->visits_alphabet);
 			alphabet_size = 5;
 		}
 
@@ -583,10 +608,17 @@ int bwb_or_align_read(bwb_or_aligner *a, const uint8_t *seq, const uint8_t *rc, 
 	for (int i = 0; i < a->alns.n; i++) free(a->alns.e[i].path);
 	a->alns.n = 0;
 	if (fresh_dseed) memset(a->Dseed, 0, sizeof(bwb_or_dlb) * ((p->seed_length > a->max_len ? p->seed_length : a->max_len) + 2));
+	if (p->use_precalc) { /* inexact_match.c:50-57 / 129-136: reads with an N in the last 12 bases of rc get an empty record */
+		/* (len < 12: read2index, align.c:174-186, reads before the buffer in the reference; the product refuses such a batch,
+		 * here the read gets an empty record) */
+		if (len < BWB_OR_PRECALC_LEN) { alns_to_bytes(&a->alns, buf, buf_len, buf_cap); return 0; }
+		for (int i = len - BWB_OR_PRECALC_LEN; i < len; i++)
+			if (rc[i] > 3) { alns_to_bytes(&a->alns, buf, buf_len, buf_cap); return 0; }
+	}
 	/* inexact_match.c:61-65 / 140-144 */
-	if (p->is_multiref) calc_d(a->x, seq, len, a->D, &a->la, &a->lb, st); else calc_d_single(a->x, seq, len, a->D);
+	if (p->is_multiref) calc_d(a->x, seq, len, a->D, &a->la, &a->lb, st); else calc_d_single(a->x, seq, len, a->D, st);
 	if (p->seed_length && len > p->seed_length) {
-		if (p->is_multiref) calc_d(a->x, seq, p->seed_length, a->Dseed, &a->la, &a->lb, st); else calc_d_single(a->x, seq, p->seed_length, a->Dseed);
+		if (p->is_multiref) calc_d(a->x, seq, p->seed_length, a->Dseed, &a->la, &a->lb, st); else calc_d_single(a->x, seq, p->seed_length, a->Dseed, st);
 	}
 	inexact_match(a, rc, len, st);
 	if (st) st->n_alignments += a->alns.n;
@@ -720,14 +752,14 @@ long bwb_or_align_fastq(const char *bwt_path, const char *fastq_path, const char
 int main(int argc, char **argv) {
 	bwb_or_params p; bwb_or_default_params(&p);
 	int c, fresh = 0;
-	while ((c = getopt(argc, argv, "M:O:E:n:k:o:e:l:m:t:SF")) >= 0) {
+	while ((c = getopt(argc, argv, "M:O:E:n:k:o:e:l:m:t:SPF")) >= 0) {
 		switch (c) {
 		case 'M': p.mm_score = atoi(optarg); break; case 'O': p.gapo_score = atoi(optarg); break;
 		case 'E': p.gape_score = atoi(optarg); break; case 'n': p.max_diff = atoi(optarg); break;
 		case 'k': p.max_diff_seed = atoi(optarg); break; case 'o': p.max_gapo = atoi(optarg); break;
 		case 'e': p.max_gape = atoi(optarg); break; case 'l': p.seed_length = atoi(optarg); break;
 		case 'm': p.max_entries = atoi(optarg); break; case 't': p.n_threads = atoi(optarg); break;
-		case 'S': p.is_multiref = 0; break; case 'F': fresh = 1; break;
+		case 'S': p.is_multiref = 0; break; case 'P': p.use_precalc = 1; break; case 'F': fresh = 1; break;
 		default: return 1;
 		}
 	}

@@ -67,6 +67,10 @@ class Oracle:
                 p.is_multiref = 0
                 i += 1
                 continue
+            if flags[i] == "-P":
+                p.use_precalc = 1
+                i += 1
+                continue
             setattr(p, _FLAG[flags[i]], int(flags[i + 1]))
             i += 2
         return p

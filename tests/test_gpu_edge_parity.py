@@ -47,7 +47,8 @@ def mid_ctx(mid, oracle):
 
 @pytest.mark.parametrize("flags", [["-n", "0"], ["-n", "2"], ["-n", "3"], ["-n", "4", "-o", "2", "-e", "4"],
                                    ["-n", "3", "-l", "0"], ["-n", "3", "-k", "0", "-l", "40"],
-                                   ["-S", "-n", "0"], ["-S", "-n", "3"], ["-S", "-n", "4", "-o", "2", "-e", "4"]])
+                                   ["-S", "-n", "0"], ["-S", "-n", "3"], ["-S", "-n", "4", "-o", "2", "-e", "4"],
+                                   ["-P", "-n", "0"], ["-P", "-n", "3"], ["-P", "-S", "-n", "2"]])
 def test_mid_genome_matches_oracle(mid_ctx, oracle, flags):
     d, fa, ctx, idx = mid_ctx
     seqs, lens = synth_reads(fa, str(d / "a.fq"), 3000, 100, 5, sub=1.5, indel=2.0, npct=2.0)
@@ -119,4 +120,5 @@ def test_force_64bit_positions(mid, oracle, monkeypatch):
     check(ctx, oracle, idx, ["-n", "3"], seqs, lens)
     check(ctx, oracle, idx, ["-n", "3", "-o", "2"], seqs, lens)
     check(ctx, oracle, idx, ["-S", "-n", "2"], seqs, lens)
+    check(ctx, oracle, idx, ["-P", "-n", "2"], seqs, lens)
     ctx.close()

@@ -58,7 +58,7 @@ def test_aln_bytes_match_reference_toy(toy_ctx, golden, name):
     assert bw.aln_bytes(off, alns) == open(os.path.join(golden, f"toy_{name}.aln"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2"])
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2", "p2"])
 def test_aln_bytes_match_reference_ragged(toy_ctx, golden, name):
     seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "ragged.fq")))
     off, alns = toy_ctx.align(bw.params(ALIGN_CONFIGS[name]), seqs, lens)
@@ -94,6 +94,7 @@ def test_empty_and_degenerate_batches(toy_ctx):
 def test_unsupported_parameters_fail_loudly(toy_ctx):
     seqs = np.zeros((1, 40), dtype=np.uint8)
     lens = np.array([40], dtype=np.uint16)
-    for flags in (["-P"], ["-o", "9"]):
-        with pytest.raises(bw.BwbError):
-            toy_ctx.align(bw.params(flags), seqs, lens)
+    with pytest.raises(bw.BwbError):
+        toy_ctx.align(bw.params(["-o", "9"]), seqs, lens)
+    with pytest.raises(bw.BwbError):  # -P with a read shorter than 12 bases (the reference reads before its buffer there)
+        toy_ctx.align(bw.params(["-P"]), seqs, np.array([11], dtype=np.uint16))

@@ -54,7 +54,7 @@ def test_index_edge_cases(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2"])
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2", "p2"])
 def test_cli_align_writes_reference_aln(toy_dir, golden, name):
     out = toy_dir / f"{name}.aln"
     log = run([bw.HOST_BIN, "align"] + ALIGN_CONFIGS[name] + [str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(out)])

@@ -55,7 +55,7 @@ def test_aln_bytes_match_reference(oracle, golden, tmp_path, name):
     assert open(out, "rb").read() == open(os.path.join(golden, f"toy_{name}.aln"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2"])
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2", "p2"])
 @pytest.mark.parametrize("threads", [1, 3])
 def test_ragged_reads_match_reference(oracle, golden, tmp_path, name, threads):
     out = str(tmp_path / "o.aln")
