@@ -8,4 +8,4 @@ avail=$(free -g | awk '/^Mem:/{print $7}')
 need=$(( MB * 40 / 1000 + 20 ))
 echo "host memory available ${avail} GB, estimated need ${need} GB"
 if [ "$avail" -lt "$need" ]; then echo "not enough host memory, skipping"; exit 0; fi
-BWB_DEBUG=1 timeout 2400 python bench.py --genome-mb $MB --reads $READS --ndiff $ND --steps 1 --warmup 0 --cpu-sample 500 2>&1 | grep -vE "^\s*$" | tail -30 | cut -c1-1500
+BWB_DEBUG=1 timeout 2400 python bench.py --genome-mb $MB --reads $READS --ndiff $ND --steps 1 --warmup 0 --cpu-sample 500 2>&1 | grep -vE "^\s*$" | tail -30 | cut -c1-4000
