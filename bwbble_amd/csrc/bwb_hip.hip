@@ -11,6 +11,7 @@
  * There is no CPU fallback anywhere in this file.
  */
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,8 @@
 #include <vector>
 #include "../../include/bwbble_hip.h"
 #include "bwb_kernels.h"
+static double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define DBG_T(what) do { if (getenv("BWB_DEBUG_T")) { hipDeviceSynchronize(); fprintf(stderr, "[bwb t] %s: %.3f s\n", what, wall_s() - dbg_t0); dbg_t0 = wall_s(); } } while (0)
 #include "bwb_lane.h"
 
 static thread_local std::string g_err;
@@ -177,20 +180,31 @@ static size_t lane_lds(const bwb_hip_ctx *c) {
 	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)2 * KID_ROWS * LANE_BLOCK * (c->pos32 ? 4 : 8);
 }
 
+/* The heap chunk pool, sized for the batch at hand and grown when a larger batch or index needs more (the pool is empty
+ * between launches, so it can be replaced at upload time).  hipMalloc costs about 27 ms per GB here: 4.7 s for the 172 GB
+ * a GRCh37-scale batch uses, which a 600-read run should not pay. */
 static int ensure_pool(bwb_hip_ctx *c) {
-	if (c->d_pool) return BWB_OK;
 	size_t fr = 0, tot = 0;
 	hipMemGetInfo(&fr, &tot);
-	/* Default: 60 % of what is free (the rest is for the scratch classes and the hit log), at most what the regions can
-	 * name: a state word holds a 26-bit chunk index relative to the block's region. */
-	size_t want = std::min<size_t>(fr / 10 * 6, (size_t)POOL_REGIONS << 36);
-	if (getenv("BWB_POOL_GB")) want = (size_t)atol(getenv("BWB_POOL_GB")) << 30;
-	if (want > fr / 10 * 7) want = fr / 10 * 7;
+	fr += c->pool_bytes; /* what would be free without the current pool */
+	/* Ceiling: 60 % of what is free (the rest is for the scratch classes and the hit log), and what the regions can name:
+	 * a state word holds a 26-bit chunk index relative to the block's region. */
+	const size_t ceiling = std::min<size_t>(fr / 10 * 6, (size_t)POOL_REGIONS << 36);
+	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
+	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
+	const size_t lanes = std::min<size_t>(std::max<uint32_t>(c->n_reads, 1), (size_t)c->num_cu * 2 * LANE_BLOCK);
+	const size_t index_mb = (size_t)(c->ix.nblk >> 13) + 1;
+	const size_t per_lane = ((size_t)c->keep << 10) + std::min<size_t>((size_t)1536 << 10, index_mb << 9);
+	size_t want = std::max<size_t>((size_t)1 << 30, lanes * per_lane / 4 * 5 * (c->wide ? 2 : 1));
+	if (want > ceiling) want = ceiling;
+	if (getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
 	if (want < ((size_t)64 << 20)) want = (size_t)64 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path) */
 	want &= ~(size_t)(POOL_REGIONS * 4096 - 1);
+	if (c->d_pool && c->pool_bytes >= want) return BWB_OK;
+	if (c->d_pool) { HIPCHK(hipFree(c->d_pool)); c->d_pool = nullptr; c->pool_bytes = 0; }
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
-	HIPCHK(hipMalloc(&c->d_pool, want));
-	HIPCHK(hipMalloc(&c->d_pool_bump, POOL_REGIONS * 64));
+	{ double dbg_t0 = wall_s(); HIPCHK(hipMalloc(&c->d_pool, want)); DBG_T("ensure_pool: hipMalloc of the pool"); }
+	if (!c->d_pool_bump) HIPCHK(hipMalloc(&c->d_pool_bump, POOL_REGIONS * 64));
 	c->pool_bytes = want;
 	return BWB_OK;
 }
@@ -225,7 +239,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
 		if (bytes + ((size_t)1 << 30) > fr) return fail(BWB_E_HIP, "not enough device memory for the per-lane scratch (class " + std::to_string(k) + ")");
-		HIPCHK(hipMalloc(&s.mem, bytes));
+		{ double dbg_t0 = wall_s(); HIPCHK(hipMalloc(&s.mem, bytes)); DBG_T("ensure_class: hipMalloc of the class scratch"); }
 		s.bytes = bytes;
 	}
 	unsigned char *base = (unsigned char *)s.mem;
@@ -255,7 +269,9 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 		for (uint32_t i = 0; i < n_reads; i++)
 			if (lens[i] < PRECALC_LEN) return fail(BWB_E_ARG, "-P needs reads of at least 12 bases (read2index, align.c:174-186, reads before the buffer otherwise)");
 	if (maxlen > 255 || maxlen > stride) return fail(BWB_E_ARG, "reads longer than 255 bases (or than stride) are not supported (aln_entry_t.i is 8-bit, align.h:104)");
+	double dbg_t0 = wall_s();
 	HIPCHK(hipSetDevice(c->device));
+	DBG_T("upload: checks + setdevice");
 	c->p = *p;
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
 	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb, p->use_precalc ? 1 : 0, p->is_multiref ? 1 : 0 };
@@ -281,6 +297,7 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 		HIPCHK(hipMemcpyAsync(c->d_reads, reads_fwd, (size_t)n_reads * stride, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipMemcpyAsync(c->d_lens, lens, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
 	}
+	DBG_T("upload: batch buffers + copies");
 	/* hit log: start at 8 records per read, grown on demand */
 	const uint64_t want = std::max<uint64_t>((uint64_t)nr * 8, 1u << 16);
 	if (c->log_cap < want) {
@@ -290,8 +307,10 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 		c->log_cap = want;
 	}
 	if (getenv("BWB_DEBUG_ITERS")) { hipFree(c->d_dbg_iters); c->d_dbg_iters = nullptr; HIPCHK(hipMalloc(&c->d_dbg_iters, nr * 4)); HIPCHK(hipMemset(c->d_dbg_iters, 0, nr * 4)); }
+	DBG_T("upload: hit log");
 	int rc = ensure_class(c, 0);
 	if (rc) return rc;
+	DBG_T("upload: ensure_class (pool + scratch)");
 	HIPCHK(hipStreamSynchronize(c->stream));
 	c->uploaded = true; c->ran = false;
 	return BWB_OK;
@@ -374,12 +393,13 @@ static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_w
 	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + per_block - 1) / per_block));
 	/* one region per 8 blocks up to POOL_REGIONS, so that the few blocks of a small launch (class 2) are not confined to
 	 * a fraction of the pool; a state word names 2^26 chunks of its region */
+	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump; /* (the pool may have been replaced since the class was set up) */
 	s.sc.n_regions = std::max<uint32_t>(1, std::min<uint32_t>(POOL_REGIONS, grid / 8));
 	s.sc.region_u4 = c->pool_bytes / s.sc.n_regions / 4096 * 256;
 	s.sc.pool_cap = (uint32_t)std::min<size_t>(s.sc.region_u4 * 16 / (c->wide ? 2048 : 1024), (size_t)1 << 26);
-	{ /* private runs take at most half of a region */
+	{ /* private runs take at most three quarters of a region */
 		const uint32_t lanes = (grid + s.sc.n_regions - 1) / s.sc.n_regions * LANE_BLOCK;
-		s.sc.keep = std::min<uint32_t>(c->keep, s.sc.pool_cap / 2 / lanes);
+		s.sc.keep = std::min<uint32_t>(c->keep, s.sc.pool_cap / 4 * 3 / lanes);
 	}
 	HIPCHK(hipEventRecord(c->ev0, c->stream));
 	if (c->pos32 && !c->wide)
@@ -538,11 +558,17 @@ extern "C" int bwb_hip_batch_result(bwb_hip_ctx *c, bwb_result *out) {
 
 extern "C" int bwb_hip_align_batch(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
                                    uint32_t n_reads, uint32_t stride, bwb_result *out) {
+	const bool dbg = getenv("BWB_DEBUG") != nullptr;
+	double t0 = wall_s();
 	int rc = bwb_hip_batch_upload(c, p, reads_fwd, lens, n_reads, stride);
 	if (rc) return rc;
+	const double t1 = wall_s();
 	rc = bwb_hip_batch_run(c);
 	if (rc) return rc;
-	return bwb_hip_batch_result(c, out);
+	const double t2 = wall_s();
+	rc = bwb_hip_batch_result(c, out);
+	if (dbg) fprintf(stderr, "[bwb] align_batch: upload %.3f s, run %.3f s, result %.3f s\n", t1 - t0, t2 - t1, wall_s() - t2);
+	return rc;
 }
 
 extern "C" int bwb_hip_calc_d(bwb_hip_ctx *c, int32_t *out_D, int32_t *out_Dseed) {

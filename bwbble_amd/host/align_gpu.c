@@ -45,8 +45,11 @@ typedef struct {
 static void *gpu_worker(void *arg) {
 	worker_t *w = (worker_t *)arg;
 	bwb_hip_ctx *ctx = NULL;
+	const int dbg = getenv("BWB_DEBUG") != NULL;
+	double tq = wall();
 	const bwtint_t hdr[5] = { w->BWT->length, w->BWT->num_words, w->BWT->num_sa, w->BWT->num_occ, w->BWT->sa0_index };
 	if (bwb_hip_ctx_create(w->gpu, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, &ctx)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->gpu, bwb_hip_last_error());
+	if (dbg) { fprintf(stderr, "[bwb host] GPU %d: context + index upload %.3f s\n", w->gpu, wall() - tq); tq = wall(); }
 	for (;;) {
 		const size_t c = atomic_fetch_add(w->cursor, 1);
 		if (c >= w->n_chunks) break;
@@ -69,8 +72,10 @@ static void *gpu_worker(void *arg) {
 		cr->alns = (bwb_aln *)malloc((tot ? tot : 1) * sizeof(bwb_aln));
 		memcpy(cr->alns, r.alns, tot * sizeof(bwb_aln));
 		atomic_store(&cr->ready, 1);
+		if (dbg) { fprintf(stderr, "[bwb host] GPU %d: chunk %zu (%u reads) %.3f s\n", w->gpu, c, n, wall() - tq); tq = wall(); }
 	}
 	bwb_hip_ctx_destroy(ctx);
+	if (dbg) fprintf(stderr, "[bwb host] GPU %d: context destroy %.3f s\n", w->gpu, wall() - tq);
 	return NULL;
 }
 
