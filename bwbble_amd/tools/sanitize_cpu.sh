@@ -1,0 +1,15 @@
+#!/bin/bash
+# Developer tool: AddressSanitizer + UBSan over the CPU-side code (the oracle and the host tools' CPU-only commands).
+# GPU sanitizers are not available on the pool, so this is the sanitizer coverage there is.  Run from the repo root.
+set -eu
+R=$(pwd); T=$(mktemp -d); G=$R/tests/golden
+gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -DBWB_ORACLE_MAIN -o $T/oracle_asan $R/oracle/bwb_oracle.c -lm
+gcc -O1 -g -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -I$R/include -o $T/bwbble_asan $R/bwbble_amd/host/*.c \
+    -L$R/bwbble_amd -lbwbble_hip -Wl,-rpath,$R/bwbble_amd -lm -lpthread
+export ASAN_OPTIONS=detect_leaks=0
+for cfg in "-n 3" "-n 4 -o 2 -e 3 -l 20 -k 1" "-S -n 2" "-P -n 2"; do $T/oracle_asan $cfg $G/toy.fa $G/ragged.fq $T/o.aln > /dev/null; done
+cmp $T/o.aln $G/ragged_p2.aln
+cp $G/toy.fa $T/ && (cd $T && ./bwbble_asan index toy.fa > /dev/null && ./bwbble_asan fasta2ref toy.fa > /dev/null)
+cmp $T/toy.fa.bwt $G/toy.fa.bwt && cmp $T/toy.fa.ann $G/toy.fa.ann
+echo "sanitizer run clean"
+rm -rf $T
