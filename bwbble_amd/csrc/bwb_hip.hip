@@ -61,7 +61,7 @@ struct bwb_hip_ctx {
 	uint4 *d_log = nullptr, *d_sorted = nullptr;
 	unsigned long long *d_count = nullptr, *d_stats = nullptr;
 	uint64_t log_cap = 0, sorted_cap = 0;
-	uint32_t dstride = 0, dseed_off = 0;
+	uint32_t dstride = 0;
 	ScratchClass cls[3];
 	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes, POOL_REGIONS equal regions */
 	size_t pool_bytes = 0;
@@ -174,7 +174,6 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 	delete c;
 }
 
-static uint32_t pad16(uint32_t v) { return (v + 15u) & ~15u; }
 
 static size_t lane_lds(const bwb_hip_ctx *c) {
 	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)2 * KID_ROWS * LANE_BLOCK * (c->pos32 ? 4 : 8);
@@ -228,9 +227,8 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	}
 	const uint32_t nslots = blocks * LANE_BLOCK;
 	const uint32_t wstride = c->maxlen + 1;
-	const uint32_t nb = (uint32_t)c->kp.num_buckets;
 	const size_t isz = c->pos32 ? 8 : 16;
-	const size_t b_bstate = (size_t)nb * nslots * 4, b_lists = (size_t)nslots * 2 * lcap * isz, b_alns = (size_t)nslots * acap * 32,
+	const size_t b_bstate = (size_t)BSTATE_ROW * nslots * 4, b_lists = (size_t)nslots * 2 * lcap * isz, b_alns = (size_t)nslots * acap * 32,
 	             b_winfo = 0;
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
 	const size_t bytes = al(b_bstate) + al(b_lists) + al(b_alns) + al(b_winfo);
@@ -277,9 +275,8 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb, p->use_precalc ? 1 : 0, p->is_multiref ? 1 : 0 };
 	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
 	c->wide = p->max_gapo > 1;
-	/* per read: u16 {D[i-1], D[i-2]} for i = 0..maxlen+1, then u16 {Dseed[si-1], Dseed[si-2]}, then the N count */
-	c->dseed_off = pad16(2 * (maxlen + 2));
-	c->dstride = 2 * c->dseed_off + 16;
+	/* per read: an 8-byte record {D pair, D_seed pair, base} for i = 0..maxlen+1, then 16 bytes (work, N count) */
+	c->dstride = 8 * (maxlen + 2) + 16;
 	const size_t nr = n_reads ? n_reads : 1;
 	if (nr > c->cap_reads || nr * stride > c->cap_readbytes || nr * c->dstride > c->cap_dbuf) {
 		free_batch(c);
@@ -319,7 +316,7 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 static Batch make_batch(bwb_hip_ctx *c, const uint32_t *worklist, uint32_t n_work) {
 	Batch b;
 	b.reads = c->d_reads; b.lens = c->d_lens; b.n_reads = c->n_reads; b.stride = c->stride;
-	b.dbuf = c->d_dbuf; b.dstride = c->dstride; b.dseed_off = c->dseed_off;
+	b.dbuf = c->d_dbuf; b.dstride = c->dstride;
 	b.worklist = worklist; b.n_work = n_work; b.counter = c->d_counter; b.status = c->d_status;
 	b.dbg_iters = c->d_dbg_iters;
 	b.iter_budget = 0; b.lane_stride = 1;

@@ -32,8 +32,9 @@ struct Batch {
 	const uint8_t *reads;     /* [n][stride] read->seq codes */
 	const uint16_t *lens;
 	uint32_t n_reads, stride;
-	uint8_t *dbuf;            /* [n][dstride]: u16 {D[i-1],D[i-2]} per position at 0, the D_seed pairs at dseed_off, N count at the end */
-	uint32_t dstride, dseed_off;
+	uint8_t *dbuf;            /* [n][dstride]: one 8-byte record per read position i: u16 {D[i-1],D[i-2]}, u16 {Dseed[si-1],Dseed[si-2]}, u8 seq[len-i];
+	                             then the read's N count (dstride-4) and its calculate_d work (dstride-8) */
+	uint32_t dstride;
 	const uint32_t *worklist; /* read ids to process (NULL = 0..n_work-1) */
 	uint32_t n_work;
 	uint32_t *counter;        /* work-stealing cursor */

@@ -19,7 +19,7 @@
  *   heap    : chains of 64-slot chunks; a lane owns a private run of `keep` chunks, what a read takes beyond them comes
  *             from the block's lock-free stack of recycled chunks or the shared pool (atomic bump allocation) and goes
  *             to that stack when the read ends.  slot 0 = header.
- *   bstate  : [bucket][slot] u32 = chunk<<6 | fill; the bucket being popped is cached in registers.
+ *   bstate  : [slot][bucket] u32 = chunk<<6 | fill; the bucket being popped is cached in registers.
  *   lists   : two SA-interval lists (cur/next) with the open tail in registers.
  *   hits    : the read's alignments (needed for the gapped-duplicate check, align.c:273-280).
  * Per-read (not per-lane) data written by k_calc_d for k_search: for every read position i = 1..len the two
@@ -35,6 +35,7 @@
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define CHUNK_SLOTS 64          /* slot 0 is the header: 63 entries per chunk */
 #define POOL_REGIONS 8
+#define BSTATE_ROW 128          /* bucket states per lane: the score range is at most 128 buckets (bwb_hip_batch_upload) */
 #define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 
@@ -46,7 +47,8 @@ struct LaneScratch {
 	unsigned int *pool_bump;    /* [POOL_REGIONS * 16] next never-used chunk of every region, 64 bytes apart */
 	uint32_t pool_cap;          /* chunks in a region */
 	uint32_t keep;              /* chunks a lane keeps for itself across reads */
-	uint32_t *bstate;           /* [nb][nslots] */
+	uint32_t *bstate;           /* [nslots][128]: a lane's bucket states are contiguous (an expansion touches scores that are
+	                               a few apart: one or two lines instead of one line per bucket) */
 	void *lists;                /* [nslots][2*lcap] Intv<P> */
 	uint4 *alns;                /* [nslots][acap*2] */
 	uint2 *winfo;               /* [nslots][wstride] */
@@ -253,10 +255,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 				if (!(kp.seed_length && len > kp.seed_length)) {
 					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads
 					 * whatever its thread's buffer holds.  We define that as the calloc'd zeros (num_diff 0, equal widths). */
-					uint16_t *Ws = (uint16_t *)(b.dbuf + (size_t)rid * b.dstride + b.dseed_off);
+					uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
 					for (int i = 1; i <= len; i++) {
 						const int si = i - (len - kp.seed_length);
-						Ws[i] = (uint16_t)((si >= 1 ? 0x80u : 0u) | (si >= 2 ? 0x8000u : 0u));
+						*(uint16_t *)(rec + 8 * i + 2) = (uint16_t)((si >= 1 ? 0x80u : 0u) | (si >= 2 ? 0x8000u : 0u));
 					}
 				}
 				if (active && kp.use_precalc) /* -P: a read with an N in the last 12 bases of rc is dropped before calculate_d (inexact_match.c:129-136) */
@@ -301,9 +303,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			const int k = plen - 1 - r; /* D index */
 			{ /* D[k] is what an entry with e->i == k+1 reads as D[i-1] and one with e->i == k+2 as D[i-2] (:317,399-405) */
 				const uint32_t byte = (uint32_t)((z > 127 ? 127 : z) | ((k > 0 && nm == prev_nm) ? 0x80 : 0));
-				uint16_t *W = (uint16_t *)(b.dbuf + (size_t)rid * b.dstride + (phase ? b.dseed_off : 0));
 				const int i1 = phase ? k + 1 + (len - kp.seed_length) : k + 1; /* seed: si = k+1  ->  i = si + len - seed_length */
-				W[i1] = (uint16_t)(byte | (prev_byte << 8));
+				uint8_t *rec = b.dbuf + (size_t)rid * b.dstride + 8 * (size_t)i1; /* what an entry with e->i == i1 needs, in one 8-byte record */
+				*(uint16_t *)(rec + (phase ? 2 : 0)) = (uint16_t)(byte | (prev_byte << 8));
+				if (!phase) rec[4] = (uint8_t)c; /* seq[len - i1]: the complement of the base the entry extends with (io.c:502-504) */
 				prev_byte = byte;
 			}
 			if (dbgD) {
@@ -353,7 +356,7 @@ template <typename P, bool WIDE> struct LHeap {
 	uint4 *pool;
 	unsigned int *pool_bump;
 	uint32_t pool_cap;
-	uint32_t *bstate;      /* this lane's column: bstate[s * nslots] */
+	uint32_t *bstate;      /* this lane's row: bstate[s] */
 	uint32_t nslots;
 	uint32_t fhead, fnext; /* chunks emptied by pops during this read (LIFO through header .x) and the link of its head */
 	uint32_t pbase, pused, keep; /* the lane's private run of `keep` consecutive chunks and how many of them this read has taken */
@@ -385,8 +388,8 @@ template <typename P, bool WIDE> struct LHeap {
 	}
 	__device__ __forceinline__ void switch_cache(int s) {
 		if (s == cb) return;
-		bstate[(size_t)cb * nslots] = cst;
-		cb = s; cst = bstate[(size_t)s * nslots];
+		bstate[cb] = cst;
+		cb = s; cst = bstate[s];
 		top_valid = false;
 	}
 	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private run of `keep` consecutive
@@ -518,10 +521,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	const uint32_t region = blockIdx.x % sc.n_regions;
 	h.pbase = ((blockIdx.x / sc.n_regions) * LANE_BLOCK + threadIdx.x) * sc.keep;
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
-	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + slot; h.nslots = sc.nslots;
+	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slot * BSTATE_ROW; h.nslots = sc.nslots;
 	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
-	for (int k = 0; k < nb; k++) h.bstate[(size_t)k * h.nslots] = NONE32;
+	for (int k = 0; k < nb; k++) h.bstate[k] = NONE32;
 
 	bool active = false, done = (threadIdx.x % b.lane_stride) != 0; /* helper-only lanes in the heavy-read pass */
 	uint32_t rid = 0;
@@ -534,8 +537,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 	int e_score = 0;
-	const uint16_t *Wd = (const uint16_t *)b.dbuf, *Ws = Wd;
-	const uint8_t *seq = b.reads;
+	const uint2 *recs = (const uint2 *)b.dbuf; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
 	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed only when the read completes */
 	unsigned long long n_iter = 0, w_iter = 0;
@@ -567,9 +569,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				r_vis_s = r_vis_a = r_pop = r_push = 0; r_iter = 0;
 				len = b.lens[rid];
-				seq = b.reads + (size_t)rid * b.stride;
-				Wd = (const uint16_t *)(b.dbuf + (size_t)rid * b.dstride);
-				Ws = (const uint16_t *)(b.dbuf + (size_t)rid * b.dstride + b.dseed_off);
+				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
+				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
 				n_alns = 0; mode = LMODE_POP; active = true;
@@ -666,12 +667,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
 		if (need_rank) {
-			wd = Wd[widx]; ws = Ws[widx];
-			const int cf = seq[len - widx]; /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
+			const uint2 rec = recs[widx]; /* one load: D[i-1], D[i-2] | D_seed pair | seq[len - widx] */
+			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
+			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
 			if (from_pop) { /* (clamped: an entry near the top score is never expanded, but the prefetch is unconditional) */
-				stX = h.bstate[(size_t)(scX < nb ? scX : nb - 1) * h.nslots];
-				stG = h.bstate[(size_t)(scG < nb ? scG : nb - 1) * h.nslots];
+				stX = h.bstate[scX < nb ? scX : nb - 1];
+				stG = h.bstate[scG < nb ? scG : nb - 1];
 			}
 			const P pl = (P)(iL - 1);
 			nvis = ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
@@ -840,8 +842,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 						STAMP(13);
 						h.num_entries += nG + nX + n0;
 						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; }
-						if (k1 > 0) { h.bstate[(size_t)scX * h.nslots] = st1 + (uint32_t)k1; h.mark(scX); }
-						if (k2 > 0) { h.bstate[(size_t)scG * h.nslots] = st2 + (uint32_t)k2; h.mark(scG); }
+						if (k1 > 0) { h.bstate[scX] = st1 + (uint32_t)k1; h.mark(scX); }
+						if (k2 > 0) { h.bstate[scG] = st2 + (uint32_t)k2; h.mark(scG); }
 					}
 				}
 			}
@@ -935,8 +937,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			/* leave every bucket state empty for the next read and give its chunks back */
 			h.release_excess();
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			h.bstate[(size_t)h.cb * h.nslots] = NONE32;
-			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[(size_t)k * h.nslots] = NONE32; h.unmark(k); }
+			h.bstate[h.cb] = NONE32;
+			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[k] = NONE32; h.unmark(k); }
 			active = false;
 		}
 	}
