@@ -75,6 +75,29 @@ __device__ __forceinline__ void lane_issue(const uint4 *__restrict__ buckets, P 
 	for (int k = 0; k < 8; k++) r.d[k] = b[k];
 }
 
+/* both sides of an SA interval: when L-1 and U fall into the same bucket (narrow intervals: most of them) the second
+ * gather is skipped and the registers are copied */
+template <typename P>
+__device__ __forceinline__ void lane_issue_pair(const uint4 *__restrict__ buckets, P last_row, P pL, P pU, LaneReq<P> &ra, LaneReq<P> &rb) {
+	lane_issue<P>(buckets, last_row, pL, ra);
+	rb.pos = pU;
+	const bool neg = (pU == (P)~(P)0), end = (pU == last_row);
+	rb.regular = !(neg || end);
+	const P blk = pU >> 7;
+	rb.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BWB_SB_SHIFT));
+	const bool same = ra.regular && rb.regular && (pL >> 7) == blk;
+	const uint4 *b = buckets + (size_t)(rb.regular ? blk : 0) * 8;
+	uint4 t[8];
+#pragma unroll
+	for (int k = 0; k < 8; k++) t[k] = ra.d[k];
+	if (!same) {
+#pragma unroll
+		for (int k = 0; k < 8; k++) t[k] = b[k];
+	}
+#pragma unroll
+	for (int k = 0; k < 8; k++) rb.d[k] = t[k];
+}
+
 /* pop[j] = #j in the bucket's block at offsets [0, pos & 127], j = 1..15 */
 template <typename P>
 __device__ __forceinline__ void lane_pops(const LaneReq<P> &r, uint32_t pop[16]) {
@@ -96,9 +119,11 @@ __device__ __forceinline__ void lane_pops(const LaneReq<P> &r, uint32_t pop[16])
 /* C[j] + Occ(j, pos) from the bucket counts (slice s: {cnt[2s], cnt[2s+1], cnt[2s+8], cnt[2s+9]}) */
 template <typename P>
 __device__ __forceinline__ P lane_val(const LaneReq<P> &r, const P *brow, const uint32_t pop[16], int j) {
-	const uint32_t *cw = (const uint32_t *)&r.d[0];
-	const int s = (j & 7) >> 1, comp = (j & 1) + 2 * (j >> 3);
-	return brow[j] + (r.regular ? (P)(cw[4 * s + comp] + pop[j]) : (P)0);
+	const int s = (j & 7) >> 1, comp = (j & 1) + 2 * (j >> 3); /* compile-time after unrolling: no pointer into r.d, so that
+	                                                              the buckets stay in registers */
+	const uint4 q = r.d[s];
+	const uint32_t cw = comp == 0 ? q.x : (comp == 1 ? q.y : (comp == 2 ? q.z : q.w));
+	return brow[j] + (r.regular ? (P)(cw + pop[j]) : (P)0);
 }
 
 #ifndef COOP_MAX_REQ
@@ -276,8 +301,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			if (s == curT - 1) { iL = cL; iU = cU; }
 			else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
 			LaneReq<P> ra, rb;
-			lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
-			lane_issue<P>(buckets, last_row, iU, rb);
+			lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
 			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
 			uint32_t ne = lane_children<P>(ra, rb, s_base, false, kidL, kidU);
 			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
@@ -682,8 +706,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 		if (nreq > COOP_MAX_REQ) {
 			if (need_rank) {
 				LaneReq<P> ra, rb;
-				lane_issue<P>(buckets, last_row, (P)(iL - 1), ra);
-				lane_issue<P>(buckets, last_row, iU, rb);
+				lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
 				ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
 			}
 		} else if (nreq > 0) {
