@@ -504,8 +504,7 @@ template <typename P, bool WIDE> struct LHeap {
 			top_valid = false;
 		} else {
 			cst--;
-			load_entry(cst, top); /* prefetch the new top: needed at the earliest by the next pop */
-			top_valid = true;
+			top_valid = false; /* the new top is fetched at the end of the iteration, unless a match pushed by then has taken its place */
 		}
 		num_entries--;
 	}
@@ -940,6 +939,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			}
 		}
 
+		if (active && !h.top_valid && h.cst != NONE32) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
+			h.load_entry(h.cst, h.top);
+			h.top_valid = true;
+		}
 		STAMP(5);
 		bool heavy = false;
 		if (active && !finish && !ovf && b.iter_budget && r_iter > b.iter_budget) { heavy = true; finish = true; }
