@@ -219,7 +219,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 		if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
 		if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
 		if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
-		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 1024; acap = 64;
+		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 4096; acap = 256;
 	} else if (k == 1) {
 		blocks = (uint32_t)c->num_cu; lcap = 8192; acap = 1024;
 	} else {
