@@ -122,3 +122,22 @@ def test_force_64bit_positions(mid, oracle, monkeypatch):
     check(ctx, oracle, idx, ["-S", "-n", "2"], seqs, lens)
     check(ctx, oracle, idx, ["-P", "-n", "2"], seqs, lens)
     ctx.close()
+
+
+def test_random_parameter_sweep(mid_ctx, oracle):
+    """Seeded random combinations of flags, read lengths and error rates (the long version is tools/fuzz_parity.py)."""
+    import random
+    d, fa, ctx, idx = mid_ctx
+    rng = random.Random(20240611)
+    for c in range(10):
+        ln = rng.choice([24, 36, 50, 76, 100, 125, 150, 200])
+        seqs, lens = synth_reads(fa, str(d / f"z{c}.fq"), rng.choice([300, 800]), ln, rng.randrange(10000),
+                                 sub=rng.choice([0.5, 1.0, 2.0, 4.0]), indel=rng.choice([0.0, 1.0, 5.0]), npct=rng.choice([0.0, 1.0, 10.0]))
+        flags = ["-n", str(rng.choice([0, 1, 2, 3, 4])), "-o", str(rng.choice([0, 1, 2, 3])), "-e", str(rng.choice([0, 2, 6])),
+                 "-l", str(rng.choice([0, 16, 32, 60])), "-k", str(rng.choice([0, 1, 2, 3])), "-M", str(rng.choice([1, 3, 5])),
+                 "-O", str(rng.choice([3, 11])), "-E", str(rng.choice([1, 4])), "-m", str(rng.choice([200, 5000, 3000000]))]
+        if rng.random() < 0.25:
+            flags.append("-S")
+        if rng.random() < 0.25:
+            flags.append("-P")
+        check(ctx, oracle, idx, flags, seqs, lens)
