@@ -17,7 +17,7 @@
 #include "bwb_host.h"
 
 /* reads per GPU batch (BWB_CHUNK): per-read work is heavy-tailed, so a batch ends with a drain phase in which few lanes
- * are busy; measured at chr21 scale, -n 3: 0.66 M reads/s with 1 M-read batches, 0.95 M reads/s with 4 M-read ones */
+ * are busy; measured at chr21 scale, -n 3: 0.75 M reads/s with 1 M-read batches, 1.19 M reads/s with 4 M-read ones */
 #define GPU_CHUNK_DEFAULT (1u << 22)
 
 static double wall(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
