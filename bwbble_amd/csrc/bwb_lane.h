@@ -554,6 +554,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	int len = 0, mode = LMODE_POP;
 	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
 	int r = 0, s = 0, curT = 0, cursel = 0, r_stop = 0;     /* exact-tail state; it ends after rc[r_stop] */
+	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* exact tail: the next interval of a multi-interval list, fetched ahead */
 	bool seeding = false;                                   /* -P: the exact steps under way build the read's first heap entries */
 	P cL = 0, cU = 0;
 	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 		} else { /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
 			widx = r + 1;
 			if (s == curT - 1) { iL = cL; iU = cU; }
+			else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous step */
 			else { const Intv<P> v = (lbase + cursel * lcap)[s]; iL = v.L; iU = v.U; }
 			need_rank = true;
 		}
@@ -890,6 +892,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < r_stop) exact_done = true; }
 				}
+				/* the interval of the next step, when it is not the list's tail (which is in registers): on its way now */
+				nxi_valid = !ovf && !exact_done && s != curT - 1;
+				if (nxi_valid) nxi = (lbase + cursel * lcap)[s];
 			}
 			if (exact_done && !ovf && seeding) {
 				/* :269-279: one entry per interval, i = readLen - 12, a 12-long all-M path; no interval: no alignment */
