@@ -1,12 +1,22 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark: 100 bp reads aligned per second on a synthetic IUPAC multi-genome, MI355X.
 
-One "step" = one pass of the hot path (k_calc_d + k_search, all scratch-class passes) over one batch of
-synthetic reads that is already resident in HBM (bwb_hip_batch_upload done before the timed region).
-Multi-GPU: one process per GPU, FM-index replicated, reads sharded (each rank aligns its own batch),
-no data-path collective; weak scaling.  See DESIGN.md "Measurement".
+Default workload = config C3 of SURVEY.md 8(d) / BASELINE.json configs[2]: GRCh37-scale synthetic multi-genome (3.1 G forward
+characters -> 6.85 G BWT rows, 64-bit positions, 6.85 GB device index), 10 M x 100 bp reads per GPU, `align -n 3`.  Genome,
+index (the product's own host indexer) and reads are built inside the run and cached under --workdir (about 4 minutes on the
+GPU box's 256 cores the first time).
 
-  python bench.py [--gpus N --steps K --warmup W] [--genome-mb 48 --reads 1000000 --ndiff 3]
+One "step" = one pass of the hot path (kl_calc_d + one slice of kl_search, include/bwbble_hip.h) over one batch of
+`--reads` reads that is resident in HBM before the timed region starts: the read pool is cut into batches, each uploaded into
+a slot of the context up front, and step s runs batch s mod n_batches.  Steps are queued back to back like the steps of any
+GPU job; the timed region ends with a flush, so every read of every step is finished inside it.
+
+Multi-GPU: one process per GPU (torch.distributed, RCCL), FM-index replicated, ONE logical FASTQ of N x pool reads cut into
+contiguous shards (rank r owns reads [r*pool, (r+1)*pool), stored as its own file), no data-path collective; weak scaling.
+`--gpus N` without a launcher starts the N ranks itself (a child `python -m torch.distributed.run`, before anything touches
+the GPU).  See DESIGN.md "Measurement".
+
+  python bench.py [--gpus N --steps K --warmup W] [--genome-mb 3100 --pool 10000000 --reads 2500000 --ndiff 3]
 """
 import argparse
 import json
@@ -14,6 +24,7 @@ import os
 import subprocess
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -21,139 +32,270 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 ALG_BYTES_PER_VISIT = 192  # one reference checkpoint row (128 B) + one packed BWT block (64 B)
+DEV_BYTES_PER_BUCKET = 128  # what the device layout fetches per rank visit (bwb_device.h)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("BWB_BENCH_GENOME_MB", 48)),
-                    help="forward characters of the synthetic genome, in millions (48 = chr21 scale, config C2)")
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("BWB_BENCH_READS", 1000000)), help="reads per GPU per step")
-    ap.add_argument("--ndiff", type=int, default=int(os.environ.get("BWB_BENCH_NDIFF", 3)), help="-n (the reference default is 0; see DESIGN.md)")
+    ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("BWB_BENCH_GENOME_MB", 3100)),
+                    help="forward characters of the synthetic genome, in millions (3100 = GRCh37 scale, config C3; 48 = chr21 scale, C2)")
+    ap.add_argument("--pool", type=int, default=int(os.environ.get("BWB_BENCH_POOL", 10000000)), help="reads per GPU in the FASTQ shard")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BWB_BENCH_READS", 2500000)), help="reads per GPU per step (one batch)")
+    ap.add_argument("--ndiff", type=int, default=int(os.environ.get("BWB_BENCH_NDIFF", 3)), help="-n (the reference default is 0; reported next to it)")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("BWB_BENCH_CPU_SAMPLE", 0)), help="reads in the CPU baseline sample (0 = auto)")
     ap.add_argument("--workdir", default=os.environ.get("BWB_BENCH_DIR", "/tmp/bwb_bench"))
-    a = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline, also.n0, end_to_end and rank_micro (profiling runs)")
+    return ap.parse_args()
 
-    import torch  # plumbing only (synchronize, barrier, max-over-ranks); imported first so that one HIP runtime is shared
+
+def self_launch(a):
+    """--gpus N without a launcher: start the N ranks as a child process.  This process has not touched the GPU (no HIP call, no
+    torch.cuda query) and only waits for the child; it never exec()s."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def wait_for(path, what, timeout=3600):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise RuntimeError(f"timed out waiting for {what}")
+        time.sleep(1.0)
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     import numpy as np
     import bwbble_amd as bw
-    from bwbble_amd import dist as bdist
-    grp = bdist.Group()  # one process per GPU; backend nccl (= RCCL) when launched by torch.distributed.run
-    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
-    barrier = grp.barrier
 
     # ---- workload: synthetic genome + index (built once, by rank 0, with the product's own indexer) ----------
     n_fwd = int(a.genome_mb * 1e6)
     os.makedirs(a.workdir, exist_ok=True)
     fa = os.path.join(a.workdir, f"genome_{n_fwd}.fa")
+    ok = fa + ".bwt.ok"
+    t_build = time.time()
     if rank == 0:
         bw.build()
-        if not os.path.exists(fa + ".bwt"):
+        if not os.path.exists(ok):
             n_rec = 1 if n_fwd <= 60_000_000 else 24
             subprocess.run([bw.SYNTH_BIN, "genome", fa, str(n_fwd), str(n_rec), str(max(4, n_fwd // 2400)), "21"], check=True)
             subprocess.run([bw.HOST_BIN, "index", fa], check=True, stdout=subprocess.DEVNULL)
-    barrier()
-    fq = os.path.join(a.workdir, f"reads_{n_fwd}_{a.reads}_{a.read_len}_r{rank}.fq")
-    if not os.path.exists(fq):
-        subprocess.run([bw.SYNTH_BIN, "reads", fa, fq, str(a.reads), str(a.read_len), str(1000 + rank), "1.0", "0.1", "0.0"], check=True)
+            if os.path.exists(fa + ".ref"):
+                os.remove(fa + ".ref")  # 2 bytes per forward character that nothing here reads
+            open(ok, "w").write("ok\n")
+    else:
+        wait_for(ok, "rank 0 to build the index")
+    a.pool = max(a.pool, a.reads)
+    fq = os.path.join(a.workdir, f"reads_{n_fwd}_{a.pool}_{a.read_len}_r{rank}.fq")  # shard `rank` of the logical FASTQ
+    if not os.path.exists(fq + ".ok"):
+        subprocess.run([bw.SYNTH_BIN, "reads", fa, fq, str(a.pool), str(a.read_len), str(1000 + rank), "1.0", "0.1", "0.0"], check=True)
+        open(fq + ".ok", "w").write("ok\n")
+    t_build = time.time() - t_build
+
+    import torch  # plumbing only (device census, barrier, max-over-ranks)
+    from bwbble_amd import dist as bdist
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+        sys.exit(f"bench.py: rank {rank} needs HIP device {local_rank}, {torch.cuda.device_count()} visible (no CPU path)")
+    grp = bdist.Group()  # one process per GPU; backend nccl (= RCCL) when launched by torch.distributed.run
+    barrier = grp.barrier
+    for r in range(world):  # every shard exists before anybody needs a neighbour's
+        wait_for(os.path.join(a.workdir, f"reads_{n_fwd}_{a.pool}_{a.read_len}_r{r}.fq.ok"), f"rank {r}'s FASTQ shard")
+
     seqs, lens = bw.load_fastq_codes(fq)
     flags = ["-n", str(a.ndiff)]
     p = bw.params(flags)
     bwt = bw.BwtFile(fa + ".bwt")
+    t0 = time.time()
     ctx = bw.Context(bwt, device=local_rank)
-    ctx.upload(p, seqs, lens)  # reads resident in HBM before any timed region
+    t_ctx = time.time() - t0
+    B = a.reads
+    nb = max(1, min(bw.MAX_SLOTS, a.pool // B))  # batches resident in HBM; step s runs batch s % nb
+    batch = lambda j: (seqs[j * B:(j + 1) * B], lens[j * B:(j + 1) * B])
+    for j in range(nb):
+        ctx.slot_upload(j, p, *batch(j))
+    ctx.flush()
 
-    for _ in range(a.warmup):
-        ctx.run()
+    def run_steps(k):
+        """k steps queued back to back; returns when all of them are complete"""
+        for s in range(k):
+            slot = s % nb
+            if s >= nb:
+                ctx.slot_wait(slot)  # its previous pass must be complete before the batch runs again
+            ctx.slot_submit(slot)
+        ctx.flush()
+
+    if a.warmup:
+        run_steps(a.warmup)
+    ctx.reset_stats()
     barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     t0 = time.perf_counter()
-    kern_ms = visits = ms_search = ms_calcd = vis_calcd = 0.0
-    for _ in range(a.steps):
-        ctx.run()  # blocks until the last kernel of the step has finished (hipStreamSynchronize inside)
-        st = ctx.stats()
-        kern_ms += st.ms_calc_d + st.ms_search  # HIP events recorded on the library's own stream, around every launch
-        ms_search += st.ms_search
-        ms_calcd += st.ms_calc_d
-        visits += st.visits_single + st.visits_alphabet
-        vis_calcd += st.visits_calc_d
+    run_steps(a.steps)  # ends with a flush: the library's streams are idle when it returns
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     barrier()
     dt = time.perf_counter() - t0
-    dt, kern_ms, visits_all = grp.reduce_step(dt, kern_ms, visits)  # MAX time over ranks, SUM of visits
-    visits = visits_all / world
     st = ctx.stats()
-    off, alns = ctx.result()
+    kern_ms = st.ms_calc_d + st.ms_search
+    visits = st.visits_single + st.visits_alphabet
+    dt, kern_ms, visits_all = grp.reduce_step(dt, kern_ms, float(visits))  # MAX time over ranks, SUM of visits
+    off0, alns0 = ctx.slot_result(0)  # hits of batch 0 = the first B reads of this shard
+
+    # every rank re-aligns a sample of its right neighbour's shard: the bytes must not depend on which GPU did the work
+    shard_check = None
+    if world > 1:
+        nbr = (rank + 1) % world
+        ns = min(2000, B)
+        nseqs, nlens = bw.load_fastq_codes(os.path.join(a.workdir, f"reads_{n_fwd}_{a.pool}_{a.read_len}_r{nbr}.fq"), max_reads=ns)
+        noff, nalns = ctx.align(p, nseqs, nlens)
+        mine = zlib.crc32(bw.aln_bytes(off0[:ns + 1], alns0[:int(off0[ns])]))
+        theirs = zlib.crc32(bw.aln_bytes(noff, nalns))
+        allc = grp.all_gather_pairs(mine, theirs)
+        shard_check = all(allc[(r + 1) % world][0] == allc[r][1] for r in range(world))
+        if not shard_check:
+            sys.exit("bench.py: a shard's sample aligned on a neighbouring GPU gave different .aln bytes")
 
     if rank != 0:
         grp.close()
         return
-    total_reads = a.reads * world * a.steps
+    total_reads = B * world * a.steps
     value = total_reads / dt
-    # Roofline of the dominant kernel (kl_search at -n > 0, kl_calc_d at -n 0): algorithmic bytes = 192 B x the rank-block
-    # visits that kernel made (counted in-kernel with the SURVEY 8(d) rule; tests assert equality with the oracle's count),
-    # divided by that kernel's launch time (HIP events on the stream it runs on).
+    # Roofline per kernel: algorithmic bytes = 192 B x the rank-block visits the kernel made (counted in-kernel with the SURVEY 8(d)
+    # rule; tests assert equality with the oracle's count), divided by the kernel's launch time (HIP events on the stream it
+    # runs on, summed over the launches of the timed region).  device_bytes = what the device layout has to move for the same work.
+    vis_calcd = st.visits_calc_d
     vis_search = visits - vis_calcd
-    k_search = {"visits_per_launch": int(vis_search / a.steps), "ms_per_launch": round(ms_search / a.steps, 3),
-                "achieved_GBs": round(vis_search * ALG_BYTES_PER_VISIT / (ms_search * 1e-3) / 1e9, 1) if ms_search else 0.0}
-    k_calcd = {"visits_per_launch": int(vis_calcd / a.steps), "ms_per_launch": round(ms_calcd / a.steps, 3),
-               "achieved_GBs": round(vis_calcd * ALG_BYTES_PER_VISIT / (ms_calcd * 1e-3) / 1e9, 1) if ms_calcd else 0.0}
-    dom_name, dom = ("kl_search", k_search) if ms_search >= ms_calcd else ("kl_calc_d", k_calcd)
-    traffic, traffic_src = None, None
-    prof = os.path.join(ROOT, "profiles", "r1_bench_profile.json")
-    if os.path.exists(prof) and (n_fwd, a.reads, a.ndiff, a.read_len) == (48_000_000, 1_000_000, 3, 100) and dom_name == "kl_search":
-        pj = json.load(open(prof))["kl_search_n3_launch"]  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-        traffic = pj["hbm_read_bytes_corrected"] + pj["hbm_write_bytes"]
-        traffic_src = "profiles/r1_bench_profile.json (FETCH_SIZE x2 per the gfx950 correction, calibrated; + WRITE_SIZE), bytes per launch"
+    def kernel(vis, ms, launches, bkt, extra_dev=0):
+        ach = vis * ALG_BYTES_PER_VISIT / (ms * 1e-3) / 1e9 if ms else 0.0
+        dev = bkt * DEV_BYTES_PER_BUCKET + extra_dev
+        return {"launches": int(launches), "ms_per_launch": round(ms / max(launches, 1), 3), "ms_total": round(ms, 3),
+                "visits_per_step": int(vis / a.steps), "algorithmic_GBs": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                "device_bytes_per_step": int(dev / a.steps), "device_GBs": round(dev / (ms * 1e-3) / 1e9, 1) if ms else 0.0,
+                "device_frac": round(dev / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else 0.0}
+    heap_bytes = (st.heap_pops + st.heap_pushes) * (32 if p.max_gapo > 1 else 16) + st.lane_iterations * 8  # heap entries + per-position records
+    k_search = kernel(vis_search, st.ms_search, st.launches_search, st.bucket_loads_search, heap_bytes)
+    k_calcd = kernel(vis_calcd, st.ms_calc_d, st.launches_calc_d, st.bucket_loads_calc_d, B * a.steps * 8 * (a.read_len + 2))
+    dom_name, dom = ("kl_search", k_search) if st.ms_search >= st.ms_calc_d else ("kl_calc_d", k_calcd)
+    traffic, traffic_src = None, "not measured in this run (PMC counters need a rocprofv3 pass; see profiles/)"
+    prof = os.path.join(ROOT, "profiles", "r2_c3_pmc.json")
+    if os.path.exists(prof):
+        pj = json.load(open(prof))
+        if (pj.get("genome_mb"), pj.get("reads"), pj.get("ndiff")) == (a.genome_mb, B, a.ndiff) and dom_name in pj:
+            traffic = pj[dom_name]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r2_c3_pmc.json: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), bytes per launch; NOT measured in this run"
     index_mb = bwt.length / 1e6  # one 128-byte bucket per 128 BWT characters
-    scale_name = "C2 chr21-scale" if n_fwd == 48_000_000 else f"{n_fwd / 1e6:.0f} M-char"
+    scale = {3_100_000_000: "C3 GRCh37-scale", 48_000_000: "C2 chr21-scale"}.get(n_fwd, f"{n_fwd / 1e6:.0f} M-char")
     residency = (f"device index {index_mb:.0f} MB: Infinity-Cache (256 MB) resident, so this is the fraction of the HBM peak reached from cache"
                  if index_mb <= 256 else f"device index {index_mb:.0f} MB: larger than the 256 MB Infinity Cache, bucket loads come from HBM")
     out = {
         "metric": "100bp reads aligned/sec (inexact BWT backward search, IUPAC FM-index)", "value": round(value, 1), "unit": "reads/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if bwt.length < 0xFFFFFFFF else "u64", "data": "synthetic",
-        "config": {"workload": f"{scale_name} synthetic multi-genome: {n_fwd} fwd chars (BWT length {bwt.length}), "
-                               f"{a.reads} x {a.read_len} bp reads per GPU, align -n {a.ndiff} (other params default)",
-                   "reads_per_gpu": a.reads, "read_len": a.read_len, "max_diff": a.ndiff, "bwt_length": int(bwt.length),
-                   "sharding": f"reads x{world}, index replicated"},
-        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": int(dom["visits_per_launch"] * ALG_BYTES_PER_VISIT),
+        "config": {"workload": f"{scale} synthetic multi-genome: {n_fwd} fwd chars (BWT length {bwt.length}), FASTQ shard of {a.pool} x {a.read_len} bp "
+                               f"reads per GPU, one step = one resident batch of {B} reads (step s runs batch s mod {nb}), align -n {a.ndiff} (other params default)",
+                   "reads_per_gpu_per_step": B, "read_pool_per_gpu": a.pool, "batches_resident": nb, "read_len": a.read_len, "max_diff": a.ndiff,
+                   "bwt_length": int(bwt.length), "sharding": f"reads x{world} (contiguous shards of one logical FASTQ), index replicated",
+                   "steps_are_pipelined": "a slice parks its unfinished reads for the next step's slice; the timed region ends with a flush"},
+        "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": dom["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac"], "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": int(dom["visits_per_step"] * a.steps / max(dom["launches"], 1) * ALG_BYTES_PER_VISIT),
                      "kernel_ms_per_launch": dom["ms_per_launch"],
                      "kernels": {"kl_search": k_search, "kl_calc_d": k_calcd},
-                     "note": residency},
-        "hits": int(off[-1]), "rerun_reads": int(st.n_overflow_reads),
+                     "lanes_busy_of_64": round(st.lane_iterations / max(st.wave_iterations, 1), 1),
+                     "reads_parked_per_step": int(st.n_parked_reads / a.steps),
+                     "note": residency + "; `achieved` counts the reference layout's 192 B per rank visit (SURVEY 8d), `device_*` the 128-byte "
+                             "buckets actually fetched (an L-1/U pair in one bucket is fetched once) plus heap entries and per-position records"},
+        "hits_batch0": int(off0[-1]), "rerun_reads": int(st.n_overflow_reads), "kernel_ms_of_step_ms": round(kern_ms / (dt * 1e3), 4),
+        "setup_s": {"genome_index_reads": round(t_build, 1), "index_to_hbm": round(t_ctx, 1)},
     }
-    # ---- CPU baseline on a bounded sample of the same workload (rank 0, N=1 only) --------------------------------
-    if world == 1:
-        out["cpu_baseline"] = cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw)
+    if shard_check is not None:
+        out["shard_sample_parity"] = shard_check
+    if world == 1 and not a.no_extras:
+        out["cpu_baseline"] = cpu_baseline(a, fa, fq, flags, off0, alns0, bw)
+        out["end_to_end"] = end_to_end(ctx, p, batch, nb, B, value)
+        out["rank_micro"] = rank_micro(ctx, index_mb)
         if a.ndiff != 0:
-            # the reference's literal CLI default is -n 0 (align.c:26): same reads, same index, reported next to the main line
-            ctx.upload(bw.params(["-n", "0"]), seqs, lens)
-            ctx.run()
-            t1 = time.perf_counter(); ctx.run(); d0 = time.perf_counter() - t1
-            s0 = ctx.stats()
-            v0 = s0.visits_single + s0.visits_alphabet
-            ach0 = s0.visits_calc_d * ALG_BYTES_PER_VISIT / (s0.ms_calc_d * 1e-3) / 1e9
-            out["also"] = {"n0": {"workload": "same batch, align -n 0 (CLI default)", "value": round(a.reads / d0, 1), "unit": "reads/s",
-                                  "ms_per_step": round(d0 * 1e3, 3), "dominant_kernel": "kl_calc_d", "kernel_ms_per_launch": round(s0.ms_calc_d, 3),
-                                  "roofline_achieved_GBs": round(ach0, 1), "roofline_frac": round(ach0 / HBM_PEAK_GBS, 4),
-                                  "visits_per_step": int(v0)}}
+            out["also"] = {"n0": also_n0(ctx, bw, batch, nb, B)}
     print(json.dumps(out))
     grp.close()
 
 
-def cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw):
+def end_to_end(ctx, p, batch, nb, B, value):
+    """The same batches with everything a caller pays: host -> pinned staging -> HBM, kernels, hit log -> host, in read order.
+    Uploads and result copies ride their own streams next to the kernels (the product's `align` loop, host/align_gpu.c)."""
+    ctx.flush()
+    t0 = time.perf_counter()
+    for j in range(nb):
+        ctx.slot_upload(j, p, *batch(j))
+        ctx.slot_submit(j)
+        if j >= 2:
+            ctx.slot_result(j - 2)
+    for j in range(max(0, nb - 2), nb):
+        ctx.slot_result(j)
+    ctx.flush()
+    dt = time.perf_counter() - t0
+    v = nb * B / dt
+    return {"value": round(v, 1), "unit": "reads/s", "batches": nb, "of_value": round(v / value, 4),
+            "includes": "H2D of reads (pinned staging), kl_calc_d + kl_search, D2H of the hit log, reordering into read order"}
+
+
+def rank_micro(ctx, index_mb):
+    """Stand-alone random Occ16: one 128-byte bucket per query, all 15 codes ranked, nothing else."""
+    n = 1 << 26
+    res = {"queries": n, "index_MB": round(index_mb, 1), "peak_GBs": HBM_PEAK_GBS}
+    for name, lane in (("octet_layout", False), ("lane_layout", True)):
+        ms, _ = ctx.rank_bench(n, iters=3, seed=7, lane=lane)
+        res[name] = {"ms": round(ms, 3), "Gvisits_per_s": round(n / ms / 1e6, 2), "device_GBs": round(n * DEV_BYTES_PER_BUCKET / ms / 1e6, 1),
+                     "device_frac": round(n * DEV_BYTES_PER_BUCKET / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "algorithmic_GBs": round(n * ALG_BYTES_PER_VISIT / ms / 1e6, 1), "algorithmic_frac": round(n * ALG_BYTES_PER_VISIT / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return res
+
+
+def also_n0(ctx, bw, batch, nb, B):
+    """the reference's literal CLI default is -n 0 (align.c:26): same reads, same index, reported next to the main line"""
+    p0 = bw.params(["-n", "0"])
+    k = min(nb, 2)
+    for j in range(k):
+        ctx.slot_upload(j, p0, *batch(j))
+    for j in range(k):
+        ctx.slot_submit(j)
+    ctx.flush()  # warm-up
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    for j in range(k):
+        ctx.slot_submit(j)
+    ctx.flush()
+    d0 = time.perf_counter() - t0
+    s0 = ctx.stats()
+    ach0 = s0.visits_calc_d * ALG_BYTES_PER_VISIT / (s0.ms_calc_d * 1e-3) / 1e9
+    dev0 = s0.bucket_loads_calc_d * DEV_BYTES_PER_BUCKET / (s0.ms_calc_d * 1e-3) / 1e9
+    return {"workload": f"{k} of the same batches, align -n 0 (CLI default)", "value": round(k * B / d0, 1), "unit": "reads/s",
+            "ms_per_step": round(d0 / k * 1e3, 3), "dominant_kernel": "kl_calc_d", "kernel_ms_per_launch": round(s0.ms_calc_d / max(s0.launches_calc_d, 1), 3),
+            "roofline_achieved_GBs": round(ach0, 1), "roofline_frac": round(ach0 / HBM_PEAK_GBS, 4),
+            "device_GBs": round(dev0, 1), "device_frac": round(dev0 / HBM_PEAK_GBS, 4),
+            "visits_per_step": int((s0.visits_single + s0.visits_alphabet) / k)}
+
+
+def cpu_baseline(a, fa, fq, flags, off, alns, bw):
     """Times the REAL reference (oracle/_ref/bwbble, OpenMP, -t all cores) when its prebuilt binary is present, else the
     CPU oracle port, on the first `sample` reads; also re-checks parity of that sample against the GPU result."""
     import oracle_lib
     cores = os.cpu_count() or 1
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "bwbble")
-    orc = oracle_lib.load()
     res = {"cores": cores, "unit": "reads/s"}
     def head_fastq(n_reads, path):
         with open(fq) as f, open(path, "w") as g:
@@ -173,13 +315,13 @@ def cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw):
         one = fq + ".one"
         head_fastq(1, one)
         t_load = t_run(one, one + ".aln")
-        probe = min(a.reads, 20000)
+        probe = min(a.reads, 2 * cores)
         sfq = fq + f".sample{probe}"
         head_fastq(probe, sfq)
         t_all = t_run(sfq, sfq + ".aln")
         sample = probe
         rate = probe / max(t_all - t_load, 1e-3)
-        want = a.cpu_sample or int(min(a.reads, rate * 15))
+        want = a.cpu_sample or int(min(a.reads, max(rate * 15, 4 * cores)))
         if want > 1.5 * probe:
             sample = want
             sfq = fq + f".sample{sample}"
@@ -190,9 +332,11 @@ def cpu_baseline(a, fa, fq, flags, seqs, lens, off, alns, bw):
         res.update({"value": round(sample / sec, 1), "kind": "reference",
                     "sample": f"first {sample} reads of the same FASTQ, oracle/_ref/bwbble align -t {cores}; wall {t_all:.2f}s minus {t_load:.2f}s load"})
     else:
-        sample = a.cpu_sample or min(a.reads, 50000)
+        orc = oracle_lib.load()
+        seqs, lens = bw.load_fastq_codes(fq, max_reads=a.cpu_sample or min(a.reads, 50000))
+        sample = len(lens)
         idx = orc.load_index(fa + ".bwt")
-        ref_bytes, _, sec = orc.align_encoded(idx, seqs[:sample], lens[:sample], orc.params(flags + ["-t", str(cores)]))
+        ref_bytes, _, sec = orc.align_encoded(idx, seqs, lens, orc.params(flags + ["-t", str(cores)]))
         res.update({"value": round(sample / sec, 1), "kind": "port",
                     "sample": f"first {sample} reads, oracle/libbwb_oracle.so with {cores} OpenMP threads, align loop only"})
     res["parity_on_sample"] = bool(bw.aln_bytes(off[:sample + 1], alns[:int(off[sample])]) == ref_bytes)

@@ -18,8 +18,10 @@ SYNTH_BIN = os.path.join(HERE, "bin", "bwb_synth")
 EXPORTS = [
     "bwb_hip_device_count", "bwb_hip_last_error", "bwb_default_params", "bwb_hip_ctx_create", "bwb_hip_ctx_destroy",
     "bwb_hip_align_batch", "bwb_hip_batch_upload", "bwb_hip_batch_run", "bwb_hip_batch_result", "bwb_hip_get_stats",
-    "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_set_sa", "bwb_hip_locate",
+    "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate",
+    "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush",
 ]
+MAX_SLOTS = 4  # BWB_MAX_SLOTS
 
 
 class Params(C.Structure):
@@ -36,7 +38,8 @@ class Result(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("visits_single", C.c_uint64), ("visits_calc_d", C.c_uint64), ("visits_alphabet", C.c_uint64), ("heap_pops", C.c_uint64),
-                ("heap_pushes", C.c_uint64), ("n_alignments", C.c_uint64), ("n_overflow_reads", C.c_uint64), ("n_heavy_reads", C.c_uint64),
+                ("heap_pushes", C.c_uint64), ("n_alignments", C.c_uint64), ("n_overflow_reads", C.c_uint64), ("n_parked_reads", C.c_uint64),
+                ("bucket_loads_search", C.c_uint64), ("bucket_loads_calc_d", C.c_uint64), ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("ms_calc_d", C.c_double), ("ms_search", C.c_double), ("ms_total", C.c_double),
                 ("launches_calc_d", C.c_uint32), ("launches_search", C.c_uint32)]
 
@@ -77,6 +80,13 @@ def lib():
         L.bwb_hip_calc_d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bwb_hip_rank16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.bwb_hip_rank_bench.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.bwb_hip_rank_bench_lane.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.bwb_hip_reset_stats.argtypes = [C.c_void_p]
+        L.bwb_hip_slot_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.bwb_hip_slot_submit.argtypes = [C.c_void_p, C.c_int]
+        L.bwb_hip_slot_wait.argtypes = [C.c_void_p, C.c_int]
+        L.bwb_hip_slot_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(Result)]
+        L.bwb_hip_flush.argtypes = [C.c_void_p]
         L.bwb_hip_set_sa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.bwb_hip_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
@@ -120,11 +130,12 @@ class BwtFile:
         self.length, self.num_words, self.num_sa, self.num_occ, self.sa0_index = (int(v) for v in hdr[:5])
         self.C = hdr[5:22].copy()
         off = 22 * 8
-        self.bwt = np.fromfile(path, dtype="<u4", count=self.num_words, offset=off)
+        # memory-mapped: a GRCh37-scale file is 12 GB, and the ranks of a multi-GPU run share its pages
+        self.bwt = np.memmap(path, dtype="<u4", mode="r", offset=off, shape=(self.num_words,))
         off += 4 * self.num_words
-        self.O = np.fromfile(path, dtype="<u8", count=self.num_occ * 16, offset=off)
+        self.O = np.memmap(path, dtype="<u8", mode="r", offset=off, shape=(self.num_occ * 16,))
         off += 8 * self.num_occ * 16
-        self.SA = np.fromfile(path, dtype="<u8", count=self.num_sa, offset=off) if load_sa else None
+        self.SA = np.memmap(path, dtype="<u8", mode="r", offset=off, shape=(self.num_sa,)) if load_sa else None
 
 
 class Context:
@@ -163,9 +174,38 @@ class Context:
     def run(self):
         _chk(lib().bwb_hip_batch_run(self._h))
 
+    # -- streaming API: up to MAX_SLOTS batches resident, slices that park instead of draining ---------------------
+    def slot_upload(self, slot, p, seqs, lens):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint16)
+        if seqs.ndim != 2 or len(lens) != seqs.shape[0]:
+            raise ValueError("seqs must be (n_reads, stride) uint8 with one length per row")
+        _chk(lib().bwb_hip_slot_upload(self._h, slot, C.byref(p), seqs.ctypes.data, lens.ctypes.data, seqs.shape[0], max(seqs.shape[1], 1)))
+
+    def slot_submit(self, slot):
+        _chk(lib().bwb_hip_slot_submit(self._h, slot))
+
+    def slot_wait(self, slot):
+        _chk(lib().bwb_hip_slot_wait(self._h, slot))
+
+    def slot_result(self, slot):
+        r = Result()
+        _chk(lib().bwb_hip_slot_result(self._h, slot, C.byref(r)))
+        return self._unpack(r)
+
+    def flush(self):
+        _chk(lib().bwb_hip_flush(self._h))
+
+    def reset_stats(self):
+        _chk(lib().bwb_hip_reset_stats(self._h))
+
     def result(self):
         r = Result()
         _chk(lib().bwb_hip_batch_result(self._h, C.byref(r)))
+        return self._unpack(r)
+
+    @staticmethod
+    def _unpack(r):
         n = r.n_reads
         off = np.ctypeslib.as_array(r.aln_off, shape=(n + 1,)).copy()
         total = int(off[n])
@@ -198,9 +238,11 @@ class Context:
         _chk(lib().bwb_hip_rank16(self._h, pos.ctypes.data, len(pos), inc, int(exact), out.ctypes.data))
         return out
 
-    def rank_bench(self, n, iters=5, seed=1):
+    def rank_bench(self, n, iters=5, seed=1, lane=False):
+        """Random Occ16 micro-benchmark: octet layout (8 lanes share a bucket) or the alignment kernels' lane layout."""
         ms, cs = C.c_double(), C.c_uint64()
-        _chk(lib().bwb_hip_rank_bench(self._h, n, iters, seed, C.byref(ms), C.byref(cs)))
+        f = lib().bwb_hip_rank_bench_lane if lane else lib().bwb_hip_rank_bench
+        _chk(f(self._h, n, iters, seed, C.byref(ms), C.byref(cs)))
         return ms.value, cs.value
 
     def set_sa(self, SA):
@@ -230,26 +272,33 @@ def encode_reads(ascii_reads):
     return seqs, lens
 
 
-def load_fastq_codes(path, max_reads=0):
-    """FASTQ -> (codes (n, stride) uint8, lens uint16) without a Python loop per read (same encoding as encode_reads)."""
+def load_fastq_codes(path, max_reads=0, chunk=500000):
+    """FASTQ -> (codes (n, stride) uint8, lens uint16) without a Python loop per read (same encoding as encode_reads);
+    the gather runs over `chunk` reads at a time so that a 10 M-read file does not need tens of GB of index temporaries."""
     data = np.fromfile(path, dtype=np.uint8)
     nl = np.flatnonzero(data == 10)
     if len(data) and data[-1] != 10:
         nl = np.append(nl, len(data))
-    starts = np.concatenate(([0], nl[:-1] + 1))
     n = len(nl) // 4
     if max_reads:
         n = min(n, max_reads)
-    s0, e0 = starts[1:4 * n:4], nl[1:4 * n:4]
+    if n == 0:
+        return np.full((0, 1), 4, dtype=np.uint8), np.zeros(0, dtype=np.uint16)
+    e0 = nl[1:4 * n:4]
+    s0 = nl[0:4 * n:4] + 1
     lens = (e0 - s0).astype(np.uint16)
-    stride = int(lens.max()) if n else 1
+    stride = int(lens.max())
     lut = np.full(256, 4, dtype=np.uint8)
     for ch, v in (("A", 0), ("G", 1), ("C", 2), ("T", 3)):
         lut[ord(ch)] = v
         lut[ord(ch.lower())] = v
-    idx = s0[:, None] + np.arange(stride)[None, :]
-    valid = np.arange(stride)[None, :] < lens[:, None]
-    seqs = np.where(valid, lut[data[np.minimum(idx, len(data) - 1)]], 4).astype(np.uint8)
+    seqs = np.empty((n, stride), dtype=np.uint8)
+    cols = np.arange(stride)[None, :]
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        idx = s0[a:b, None] + cols
+        valid = cols < lens[a:b, None]
+        seqs[a:b] = np.where(valid, lut[data[np.minimum(idx, len(data) - 1)]], 4)
     return seqs, lens
 
 

@@ -1,13 +1,20 @@
 /*
  * bwb_hip.hip - C-ABI implementation of include/bwbble_hip.h (libbwbble_hip.so), MI355X / gfx950 only.
  *
- * Host orchestration of one batch (replaces the per-batch body of align_reads_inexact_parallel,
- * mg-aligner/inexact_match.c:103-165):
- *   1. kl_calc_d over all reads (one read per lane, lanes pull reads from a global cursor);
- *   2. kl_search over all reads with the class-0 per-lane scratch and the shared heap chunk pool; reads whose
- *      interval list / hit list did not fit, or that found the pool empty, are re-run -- still on the GPU --
- *      in class 1, then class 2 (fewer lanes, larger lists, a fresh pool);
- *   3. hits gathered into read order.
+ * Host orchestration (replaces the per-batch body of align_reads_inexact_parallel, mg-aligner/inexact_match.c:103-165).
+ * A context keeps up to BWB_MAX_SLOTS batches of reads resident ("slots") and runs them as a stream:
+ *
+ *   slot_upload(s)  reads -> pinned staging -> HBM on the copy stream                        (overlaps the kernels)
+ *   slot_submit(s)  kl_calc_d over the slot, then ONE SLICE of kl_search fed from the slot's cursor.  With more batches to
+ *                   come the slice does not drain: when the cursor runs out, waves park the reads they are working on in
+ *                   the lanes' save area (bwb_lane.h) and the next slot's slice resumes them, so the heavy tail of batch k
+ *                   runs next to the bulk of batch k+1 instead of on a nearly empty GPU.
+ *   slot_wait(s)    until every read of the slot is done (normally when the following slice ends; a draining launch
+ *                   otherwise), then the rare reads that did not fit the class-0 per-read scratch are re-run - still on the
+ *                   GPU - in class 1, then class 2 (fewer lanes, larger lists, their own chunk pool)
+ *   slot_result(s)  hit log -> host on the result stream, put into read order
+ *
+ * batch_upload / batch_run / batch_result are the same on slot 0 with a draining slice (one batch, nothing to overlap).
  * There is no CPU fallback anywhere in this file.
  */
 #include <hip/hip_runtime.h>
@@ -16,12 +23,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/bwbble_hip.h"
 #include "bwb_kernels.h"
 static double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-#define DBG_T(what) do { if (getenv("BWB_DEBUG_T")) { hipDeviceSynchronize(); fprintf(stderr, "[bwb t] %s: %.3f s\n", what, wall_s() - dbg_t0); dbg_t0 = wall_s(); } } while (0)
 #include "bwb_lane.h"
 
 static thread_local std::string g_err;
@@ -32,49 +39,109 @@ static int fail(int code, const std::string &m) { g_err = m; return code; }
 		if (e_ != hipSuccess) return fail(BWB_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_));  \
 	} while (0)
 
-/* per-lane scratch of one class (class 0 = every resident lane, classes 1/2 = fewer lanes with larger lists) */
-struct ScratchClass {
-	void *mem = nullptr;
+/* device / pinned-host allocations that free themselves: an early error return leaks nothing */
+struct DevMem {
+	void *p = nullptr;
 	size_t bytes = 0;
-	LaneScratch sc{};
-	uint32_t blocks = 0;
+	DevMem() = default;
+	DevMem(const DevMem &) = delete;
+	DevMem &operator=(const DevMem &) = delete;
+	~DevMem() { release(); }
+	void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+	hipError_t alloc(size_t n) { release(); hipError_t e = hipMalloc(&p, n ? n : 1); if (e == hipSuccess) bytes = n; else p = nullptr; return e; }
+	hipError_t reserve(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(n); } /* contents are NOT kept */
+	template <typename T> T *as() const { return (T *)p; }
+};
+struct PinMem {
+	void *p = nullptr;
+	size_t bytes = 0;
+	PinMem() = default;
+	PinMem(const PinMem &) = delete;
+	PinMem &operator=(const PinMem &) = delete;
+	~PinMem() { if (p) (void)hipHostFree(p); }
+	hipError_t reserve(size_t n) {
+		if (p && bytes >= n) return hipSuccess;
+		if (p) (void)hipHostFree(p);
+		p = nullptr; bytes = 0;
+		hipError_t e = hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault);
+		if (e == hipSuccess) bytes = n; else p = nullptr;
+		return e;
+	}
+	template <typename T> T *as() const { return (T *)p; }
+};
+struct Event {
+	hipEvent_t e = nullptr;
+	Event() = default;
+	Event(const Event &) = delete;
+	Event &operator=(const Event &) = delete;
+	~Event() { if (e) (void)hipEventDestroy(e); }
+	hipError_t create() { return e ? hipSuccess : hipEventCreate(&e); }
 };
 
-struct bwb_hip_ctx {
-	int device = 0, num_cu = 0;
-	hipStream_t stream = nullptr;
-	DevIndex ix{};
-	uint4 *d_buckets = nullptr;
-	uint64_t sa0_index = 0, num_sa = 0;
-	uint64_t *d_SA = nullptr;
-	bool pos32 = true;                  /* BWT rows fit 32-bit positions */
-	/* batch */
-	bool uploaded = false, ran = false;
-	bwb_params p{};
-	KParams kp{};
-	uint32_t n_reads = 0, stride = 0, maxlen = 0;
-	size_t cap_reads = 0, cap_readbytes = 0, cap_dbuf = 0;
-	uint8_t *d_reads = nullptr, *d_dbuf = nullptr, *d_status = nullptr;
-	uint16_t *d_lens = nullptr;
-	uint32_t *d_counter = nullptr, *d_worklist = nullptr, *d_n = nullptr;
-	uint64_t *d_off = nullptr, *d_dstoff = nullptr;
-	uint4 *d_log = nullptr, *d_sorted = nullptr;
-	unsigned long long *d_count = nullptr, *d_stats = nullptr;
-	uint64_t log_cap = 0, sorted_cap = 0;
-	uint32_t dstride = 0;
-	ScratchClass cls[3];
-	uint4 *d_pool = nullptr;            /* heap chunk pool shared by all lanes and classes, POOL_REGIONS equal regions */
-	size_t pool_bytes = 0;
-	unsigned int *d_pool_bump = nullptr;
-	uint32_t keep = 256;                /* chunks of a lane's private run (BWB_KEEP) */
-	uint32_t *d_dbg_iters = nullptr;    /* BWB_DEBUG_ITERS: per-read iteration counts */
-	int bpc_search = 2, bpc_calcd = 2;
-	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
+/* per-lane scratch of one class (class 0 = every resident lane, classes 1/2 = fewer lanes with larger lists) */
+struct ScratchClass {
+	DevMem mem;
+	LaneScratch sc{};
+	uint32_t blocks = 0;
+	bool ready = false;
+};
+
+/* one resident batch */
+struct Slot {
+	bool uploaded = false, submitted = false, complete = false, fetched = false;
+	uint32_t n_reads = 0, stride = 0, maxlen = 0, dstride = 0;
+	DevMem d_reads, d_lens, d_dbuf, d_status, d_n, d_off, d_worklist, d_log, d_ctl, d_dbg_iters;
+	uint64_t log_cap = 0;
+	PinMem h_reads, h_lens, h_cnt, h_off, h_log, h_ctl;
 	std::vector<uint8_t> h_status;
 	std::vector<uint64_t> h_aln_off;
 	std::vector<bwb_aln> h_alns;
+	Event ev_up;
+	uint64_t launch = 0;          /* sequence number of the slice that was fed from this slot */
+	/* control words on the device (d_ctl, 64 bytes apart): the work cursor, the number of finished reads, the hit count */
+	uint32_t *ctl_counter() const { return d_ctl.as<uint32_t>(); }
+	unsigned int *ctl_done() const { return d_ctl.as<unsigned int>() + 16; }
+	unsigned long long *ctl_count() const { return (unsigned long long *)(d_ctl.as<unsigned char>() + 128); }
+	uint32_t *ctl_counter2() const { return d_ctl.as<uint32_t>() + 48; } /* cursor of the re-run launches */
+};
+
+struct PendingTime { hipEvent_t e0, e1; int kind; }; /* kind 0 = kl_calc_d, 1 = kl_search */
+
+struct bwb_hip_ctx {
+	int device = 0, num_cu = 0;
+	hipStream_t stream = nullptr, cstream = nullptr, rstream = nullptr; /* kernels; uploads; results */
+	DevIndex ix{};
+	DevMem d_buckets, d_SA, d_stats, d_descs, d_misc;
+	uint64_t sa0_index = 0, num_sa = 0;
+	bool pos32 = true;                  /* BWT rows fit 32-bit positions */
+	bwb_params p{};
+	KParams kp{};
+	bool have_params = false;
+	Slot slots[BWB_MAX_SLOTS];
+	SlotDesc h_descs[BWB_MAX_SLOTS]{};
+	ScratchClass cls[3];
+	DevMem d_pool, d_pool2, d_pool_bump;  /* heap chunk pools (class 0; classes 1-2), POOL_REGIONS equal regions; bump counters (two sets) */
+	uint32_t keep = 256;                /* chunks of a lane's private run (BWB_KEEP) */
+	int bpc_search = 2, bpc_calcd = 2;
+	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
+	bool parked = false;                /* reads may be parked in the class-0 save area (the last class-0 launch was a non-draining slice) */
+	uint64_t n_launches = 0;            /* class-0 search launches so far */
+	std::vector<hipEvent_t> launch_ev;  /* launch_ev[k-1]: recorded after class-0 search launch k */
+	std::vector<PendingTime> pending;
+	std::vector<hipEvent_t> free_events;
+	uint32_t slice_iters = 0;           /* BWB_SLICE_ITERS: test knob, time-sliced launches */
+	bool force_slices = false;          /* BWB_FORCE_SLICES: the one-batch API parks and resumes too (tests) */
+	bool dbg = false, dbg_iters = false;
 	bwb_stats stats{};
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	double t_run0 = 0;
+	~bwb_hip_ctx() {
+		for (auto &pt : pending) { (void)hipEventDestroy(pt.e0); (void)hipEventDestroy(pt.e1); }
+		for (auto e : free_events) (void)hipEventDestroy(e);
+		for (auto e : launch_ev) (void)hipEventDestroy(e);
+		if (stream) (void)hipStreamDestroy(stream);
+		if (cstream) (void)hipStreamDestroy(cstream);
+		if (rstream) (void)hipStreamDestroy(rstream);
+	}
 };
 
 extern "C" const char *bwb_hip_last_error(void) { return g_err.c_str(); }
@@ -92,6 +159,13 @@ extern "C" void bwb_default_params(bwb_params *p) { /* set_default_aln_params, a
 	p->is_multiref = 1; p->max_best = 30; p->no_indel_length = 5; p->n_threads = 1;
 }
 
+/* D2H of a few bytes without touching the null stream (which would wait for every queued slice) */
+static int fetch(bwb_hip_ctx *c, void *dst, const void *src, size_t n) {
+	HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->rstream));
+	HIPCHK(hipStreamSynchronize(c->rstream));
+	return BWB_OK;
+}
+
 extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
                                   const uint64_t *O, bwb_hip_ctx **out) {
 	if (!hdr || !C || !bwt || !O || !out) return fail(BWB_E_ARG, "ctx_create: null argument");
@@ -99,20 +173,25 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	const uint64_t nblk = (length + 127) / 128;
 	if (length < 2 || num_occ != nblk || num_words != (length + 7) / 8) return fail(BWB_E_ARG, "ctx_create: inconsistent .bwt header");
 	const uint64_t nsb = (nblk + (1ull << BWB_SB_SHIFT) - 1) >> BWB_SB_SHIFT;
-	if (nsb > BWB_NSB_MAX) return fail(BWB_E_ARG, "ctx_create: index larger than 2^34 characters");
+	if (nsb > BWB_NSB_MAX) return fail(BWB_E_ARG, "ctx_create: index larger than the superblock table covers (2^34 characters)");
 	HIPCHK(hipSetDevice(device));
-	bwb_hip_ctx *c = new bwb_hip_ctx();
+	std::unique_ptr<bwb_hip_ctx> c(new bwb_hip_ctx()); /* freed with everything it owns on any early return */
 	c->device = device;
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 	c->num_cu = prop.multiProcessorCount;
-	HIPCHK(hipStreamCreate(&c->stream));
-	HIPCHK(hipEventCreate(&c->ev0));
-	HIPCHK(hipEventCreate(&c->ev1));
-	HIPCHK(hipMalloc(&c->d_buckets, nblk * 128));
-	HIPCHK(hipMalloc(&c->d_counter, 64));
-	HIPCHK(hipMalloc(&c->d_count, 64));
-	HIPCHK(hipMalloc(&c->d_stats, sizeof(unsigned long long) * 40));
+	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking));
+	HIPCHK(c->d_buckets.alloc(nblk * 128));
+	HIPCHK(c->d_stats.alloc(sizeof(unsigned long long) * STAT_WORDS));
+	HIPCHK(c->d_descs.alloc(sizeof(SlotDesc) * BWB_MAX_SLOTS));
+	HIPCHK(c->d_misc.alloc(256));
+	HIPCHK(hipMemsetAsync(c->d_stats.p, 0, sizeof(unsigned long long) * STAT_WORDS, c->stream));
+	c->dbg = getenv("BWB_DEBUG") != nullptr;
+	c->dbg_iters = getenv("BWB_DEBUG_ITERS") != nullptr;
+	if (getenv("BWB_SLICE_ITERS")) c->slice_iters = (uint32_t)strtoul(getenv("BWB_SLICE_ITERS"), nullptr, 10);
+	c->force_slices = getenv("BWB_FORCE_SLICES") != nullptr || c->slice_iters != 0;
 
 	/* superblock base table */
 	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
@@ -125,73 +204,72 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	for (uint64_t sb = 0; sb < BWB_NSB_MAX; sb++)
 		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
 	for (int j = 0; j < 16; j++) { c->ix.base[BWB_ROW_NEG][j] = C[j]; c->ix.base[BWB_ROW_END][j] = C[j + 1]; }
-	c->ix.buckets = c->d_buckets;
+	c->ix.buckets = c->d_buckets.as<uint4>();
 	c->ix.length = length;
 	c->ix.nblk = nblk;
 	c->sa0_index = hdr[4];
 	c->pos32 = length < 0xFFFFFFFFull && !getenv("BWB_FORCE_POS64");
 
-	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk */
+	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk; the two staging sets alternate so that the copy of
+	 * chunk k+1 overlaps the kernel of chunk k */
 	const uint64_t CH = 1ull << 20;
-	uint32_t *d_bwt = nullptr; uint64_t *d_O = nullptr, *d_sbc = nullptr;
-	HIPCHK(hipMalloc(&d_bwt, std::min(CH, nblk) * 64));
-	HIPCHK(hipMalloc(&d_O, std::min(CH, nblk) * 128));
-	HIPCHK(hipMalloc(&d_sbc, sbcount.size() * 8));
-	HIPCHK(hipMemcpy(d_sbc, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice));
-	for (uint64_t b0 = 0; b0 < nblk; b0 += CH) {
+	DevMem d_bwt[2], d_O[2], d_sbc;
+	Event ev_k[2];
+	for (int t = 0; t < 2; t++) {
+		HIPCHK(d_bwt[t].alloc(std::min(CH, nblk) * 64));
+		HIPCHK(d_O[t].alloc(std::min(CH, nblk) * 128));
+		HIPCHK(ev_k[t].create());
+	}
+	HIPCHK(d_sbc.alloc(sbcount.size() * 8));
+	HIPCHK(hipMemcpyAsync(d_sbc.p, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	int t = 0;
+	for (uint64_t b0 = 0; b0 < nblk; b0 += CH, t ^= 1) {
 		const uint64_t nb = std::min(CH, nblk - b0);
 		const uint64_t w0 = b0 * 16, nw = std::min(nb * 16, num_words - w0);
-		HIPCHK(hipMemcpy(d_bwt, bwt + w0, nw * 4, hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(d_O, O + b0 * 16, nb * 128, hipMemcpyHostToDevice));
+		HIPCHK(hipEventSynchronize(ev_k[t].e)); /* the kernel that read this staging set two chunks ago */
+		HIPCHK(hipMemcpyAsync(d_bwt[t].p, bwt + w0, nw * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_O[t].p, O + b0 * 16, nb * 128, hipMemcpyHostToDevice, c->stream));
 		const uint64_t nthreads = nb * 8;
-		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt, d_O, b0, nb, nw, hdr[4], d_sbc, c->d_buckets);
+		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt[t].as<uint32_t>(), d_O[t].as<uint64_t>(), b0, nb, nw,
+		                   hdr[4], d_sbc.as<uint64_t>(), c->d_buckets.as<uint4>());
 		HIPCHK(hipGetLastError());
-		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(hipEventRecord(ev_k[t].e, c->stream));
 	}
-	hipFree(d_bwt); hipFree(d_O); hipFree(d_sbc);
-	*out = c;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	*out = c.release();
 	return BWB_OK;
-}
-
-static void free_batch(bwb_hip_ctx *c) {
-	hipFree(c->d_reads); hipFree(c->d_lens); hipFree(c->d_dbuf); hipFree(c->d_status); hipFree(c->d_worklist);
-	hipFree(c->d_n); hipFree(c->d_off); hipFree(c->d_dstoff);
-	c->d_reads = c->d_dbuf = c->d_status = nullptr; c->d_lens = nullptr; c->d_worklist = c->d_n = nullptr; c->d_off = c->d_dstoff = nullptr;
-	c->cap_reads = c->cap_readbytes = c->cap_dbuf = 0;
 }
 
 extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 	if (!c) return;
-	hipSetDevice(c->device);
-	free_batch(c);
-	for (auto &k : c->cls) hipFree(k.mem);
-	hipFree(c->d_pool); hipFree(c->d_pool_bump);
-	hipFree(c->d_log); hipFree(c->d_sorted); hipFree(c->d_buckets); hipFree(c->d_counter); hipFree(c->d_count);
-	hipFree(c->d_stats); hipFree(c->d_SA);
-	if (c->ev0) hipEventDestroy(c->ev0);
-	if (c->ev1) hipEventDestroy(c->ev1);
-	if (c->stream) hipStreamDestroy(c->stream);
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
 	delete c;
 }
-
 
 static size_t lane_lds(const bwb_hip_ctx *c) {
 	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)2 * KID_ROWS * LANE_BLOCK * (c->pos32 ? 4 : 8);
 }
 
-/* The heap chunk pool, sized for the batch at hand and grown when a larger batch or index needs more (the pool is empty
- * between launches, so it can be replaced at upload time).  hipMalloc costs about 27 ms per GB here: 4.7 s for the 172 GB
- * a GRCh37-scale batch uses, which a 600-read run should not pay. */
+static uint32_t max_reads_resident(const bwb_hip_ctx *c) {
+	uint32_t n = 1;
+	for (const Slot &s : c->slots) n = std::max(n, s.n_reads);
+	return n;
+}
+
+/* The class-0 heap chunk pool, sized for the batches at hand and grown when a larger batch or index needs more (it can be
+ * replaced only while no read is parked).  hipMalloc costs about 27 ms per GB here, which a 600-read run should not pay. */
 static int ensure_pool(bwb_hip_ctx *c) {
 	size_t fr = 0, tot = 0;
-	hipMemGetInfo(&fr, &tot);
-	fr += c->pool_bytes; /* what would be free without the current pool */
-	/* Ceiling: 60 % of what is free (the rest is for the scratch classes and the hit log), and what the regions can name:
-	 * a state word holds a 26-bit chunk index relative to the block's region. */
-	const size_t ceiling = std::min<size_t>(fr / 10 * 6, (size_t)POOL_REGIONS << 36);
+	HIPCHK(hipMemGetInfo(&fr, &tot));
+	fr += c->d_pool.bytes; /* what would be free without the current pool */
+	/* Ceiling: half of what is free (the rest is for the scratch classes, their pool and the slots), and what the regions can
+	 * name: a state word holds a 26-bit chunk index relative to the block's region. */
+	const size_t ceiling = std::min<size_t>(fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
 	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
-	const size_t lanes = std::min<size_t>(std::max<uint32_t>(c->n_reads, 1), (size_t)c->num_cu * 2 * LANE_BLOCK);
+	const size_t lanes = std::min<size_t>(max_reads_resident(c), (size_t)c->num_cu * 2 * LANE_BLOCK);
 	const size_t index_mb = (size_t)(c->ix.nblk >> 13) + 1;
 	const size_t per_lane = ((size_t)c->keep << 10) + std::min<size_t>((size_t)1536 << 10, index_mb << 9);
 	size_t want = std::max<size_t>((size_t)1 << 30, lanes * per_lane / 4 * 5 * (c->wide ? 2 : 1));
@@ -199,61 +277,107 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	if (getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
 	if (want < ((size_t)64 << 20)) want = (size_t)64 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path) */
 	want &= ~(size_t)(POOL_REGIONS * 4096 - 1);
-	if (c->d_pool && c->pool_bytes >= want) return BWB_OK;
-	if (c->d_pool) { HIPCHK(hipFree(c->d_pool)); c->d_pool = nullptr; c->pool_bytes = 0; }
+	if (c->d_pool.p && c->d_pool.bytes >= want) return BWB_OK;
+	if (c->parked) return BWB_OK; /* parked reads hold chunks of the present pool: keep it (the admission control copes) */
+	c->d_pool.release();
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
-	{ double dbg_t0 = wall_s(); HIPCHK(hipMalloc(&c->d_pool, want)); DBG_T("ensure_pool: hipMalloc of the pool"); }
-	if (!c->d_pool_bump) HIPCHK(hipMalloc(&c->d_pool_bump, POOL_REGIONS * 64));
-	c->pool_bytes = want;
+	HIPCHK(c->d_pool.alloc(want));
+	if (!c->d_pool_bump.p) HIPCHK(c->d_pool_bump.alloc(2 * POOL_REGIONS * 64));
+	return BWB_OK;
+}
+
+/* the pool of the re-run classes: separate, because class-0 reads may be parked (holding class-0 chunks) while a re-run runs */
+static int ensure_pool2(bwb_hip_ctx *c) {
+	if (c->d_pool2.p) return BWB_OK;
+	size_t fr = 0, tot = 0;
+	HIPCHK(hipMemGetInfo(&fr, &tot));
+	size_t want = std::min<size_t>((size_t)16 << 30, fr / 4);
+	if (getenv("BWB_POOL_GB")) want = std::max<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, (size_t)256 << 20);
+	want = std::max<size_t>(want, (size_t)64 << 20) & ~(size_t)(POOL_REGIONS * 4096 - 1);
+	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the chunk pool of the re-run classes");
+	HIPCHK(c->d_pool2.alloc(want));
+	if (!c->d_pool_bump.p) HIPCHK(c->d_pool_bump.alloc(2 * POOL_REGIONS * 64));
 	return BWB_OK;
 }
 
 static int ensure_class(bwb_hip_ctx *c, int k) {
-	int rc = ensure_pool(c);
-	if (rc) return rc;
 	ScratchClass &s = c->cls[k];
 	uint32_t blocks, lcap, acap;
 	if (k == 0) {
 		/* 2 blocks (8 waves) per CU for both kernels (a third kl_calc_d block per CU measured no faster) */
-		c->bpc_search = 2; c->bpc_calcd = 2;
-		if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
-		if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
-		if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
+		if (!s.ready) {
+			c->bpc_search = 2; c->bpc_calcd = 2;
+			if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
+			if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
+			if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
+		}
 		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 4096; acap = 256;
 	} else if (k == 1) {
-		blocks = (uint32_t)c->num_cu; lcap = 8192; acap = 1024;
+		blocks = (uint32_t)std::max(1, c->num_cu / 2); lcap = 8192; acap = 1024;
 	} else {
 		blocks = 4; lcap = 1u << 20; acap = 1u << 16;
 	}
+	int rc = k == 0 ? ensure_pool(c) : ensure_pool2(c);
+	if (rc) return rc;
 	const uint32_t nslots = blocks * LANE_BLOCK;
-	const uint32_t wstride = c->maxlen + 1;
 	const size_t isz = c->pos32 ? 8 : 16;
-	const size_t b_bstate = (size_t)BSTATE_ROW * nslots * 4, b_lists = (size_t)nslots * 2 * lcap * isz, b_alns = (size_t)nslots * acap * 32,
-	             b_winfo = 0;
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-	const size_t bytes = al(b_bstate) + al(b_lists) + al(b_alns) + al(b_winfo);
-	if (!(s.mem && s.bytes >= bytes)) {
-		if (s.mem) { hipFree(s.mem); s.mem = nullptr; }
+	const size_t b_bstate = al((size_t)BSTATE_ROW * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
+	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16);
+	/* class 0 runs kl_calc_d of the next batch while parked reads keep their lists: it gets a second set; the re-run classes
+	 * are drained before anything else uses them */
+	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_save + b_bsave;
+	if (!(s.mem.p && s.mem.bytes >= bytes)) {
+		if (k == 0 && c->parked) return fail(BWB_E_STATE, "the class-0 scratch cannot grow while reads are parked (flush first)");
+		s.mem.release();
 		size_t fr = 0, tot = 0;
-		hipMemGetInfo(&fr, &tot);
+		HIPCHK(hipMemGetInfo(&fr, &tot));
 		if (bytes + ((size_t)1 << 30) > fr) return fail(BWB_E_HIP, "not enough device memory for the per-lane scratch (class " + std::to_string(k) + ")");
-		{ double dbg_t0 = wall_s(); HIPCHK(hipMalloc(&s.mem, bytes)); DBG_T("ensure_class: hipMalloc of the class scratch"); }
-		s.bytes = bytes;
+		HIPCHK(s.mem.alloc(bytes));
+		HIPCHK(hipMemsetAsync((unsigned char *)s.mem.p + bytes - b_save - b_bsave, 0, b_save + b_bsave, c->stream));
 	}
-	unsigned char *base = (unsigned char *)s.mem;
-	s.sc.bstate = (uint32_t *)base; base += al(b_bstate);
-	s.sc.lists = (void *)base; base += al(b_lists);
-	s.sc.alns = (uint4 *)base; base += al(b_alns);
-	s.sc.winfo = (uint2 *)base;
-	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = wstride;
-	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump; s.sc.keep = c->keep;
+	unsigned char *base = s.mem.as<unsigned char>();
+	s.sc.bstate = (uint32_t *)base; base += b_bstate;
+	s.sc.lists = (void *)base; base += b_lists;
+	s.sc.lists_d = s.sc.lists;
+	if (k == 0) { s.sc.lists_d = (void *)base; base += b_lists; }
+	s.sc.alns = (uint4 *)base; base += b_alns;
+	s.sc.save = (uint4 *)base; base += b_save;
+	s.sc.blocksave = (uint32_t *)base;
+	s.sc.winfo = nullptr;
+	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = 0;
+	s.sc.keep = c->keep;
 	s.blocks = blocks;
+	s.ready = true;
 	return BWB_OK;
 }
 
-extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
-                                    uint32_t n_reads, uint32_t stride) {
-	if (!c || !p || (n_reads && (!reads_fwd || !lens)) || stride == 0) return fail(BWB_E_ARG, "batch_upload: bad argument");
+static hipEvent_t get_event(bwb_hip_ctx *c) {
+	if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;
+	return e;
+}
+
+/* adds the HIP-event time of every finished launch to the statistics (all of them when `all`: the stream must be idle then) */
+static int resolve_times(bwb_hip_ctx *c, bool all) {
+	size_t w = 0;
+	for (size_t i = 0; i < c->pending.size(); i++) {
+		PendingTime &pt = c->pending[i];
+		const bool ready = all || hipEventQuery(pt.e1) == hipSuccess;
+		if (!ready) { c->pending[w++] = pt; continue; }
+		if (all) HIPCHK(hipEventSynchronize(pt.e1));
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, pt.e0, pt.e1));
+		if (pt.kind == 0) { c->stats.ms_calc_d += ms; c->stats.launches_calc_d++; }
+		else { c->stats.ms_search += ms; c->stats.launches_search++; }
+		c->free_events.push_back(pt.e0); c->free_events.push_back(pt.e1);
+	}
+	c->pending.resize(w);
+	return BWB_OK;
+}
+
+static int check_params(const bwb_params *p, int *nb_out) {
 	if (p->max_gapo < 0 || p->max_gapo > 4) return fail(BWB_E_ARG, "max_gapo (-o) must be in [0,4] on the GPU path");
 	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
 	if (p->seed_length < 0 || p->seed_length > 255) return fail(BWB_E_ARG, "seed_length must be in [0,255]");
@@ -261,301 +385,481 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	const int nb = (p->max_diff + 1) * p->mm_score + (p->max_gapo + 1) * p->gapo_score + (p->max_gape + 1) * p->gape_score; /* heap_init :513 */
 	if (nb < 1 || nb > 128) return fail(BWB_E_ARG, "score range (heap buckets) must be in [1,128]");
 	if (p->max_entries < 1) return fail(BWB_E_ARG, "max_entries must be positive");
-	uint32_t maxlen = 0;
-	for (uint32_t i = 0; i < n_reads; i++) maxlen = std::max<uint32_t>(maxlen, lens[i]);
-	if (p->use_precalc)
-		for (uint32_t i = 0; i < n_reads; i++)
-			if (lens[i] < PRECALC_LEN) return fail(BWB_E_ARG, "-P needs reads of at least 12 bases (read2index, align.c:174-186, reads before the buffer otherwise)");
-	if (maxlen > 255 || maxlen > stride) return fail(BWB_E_ARG, "reads longer than 255 bases (or than stride) are not supported (aln_entry_t.i is 8-bit, align.h:104)");
-	double dbg_t0 = wall_s();
+	*nb_out = nb;
+	return BWB_OK;
+}
+
+static bool any_in_flight(const bwb_hip_ctx *c) {
+	for (const Slot &s : c->slots) if (s.submitted && !s.complete) return true;
+	return false;
+}
+
+static int slot_wait(bwb_hip_ctx *c, int si);
+
+extern "C" int bwb_hip_flush(bwb_hip_ctx *c) {
+	if (!c) return fail(BWB_E_ARG, "flush: null context");
 	HIPCHK(hipSetDevice(c->device));
-	DBG_T("upload: checks + setdevice");
-	c->p = *p;
+	for (int s = 0; s < BWB_MAX_SLOTS; s++)
+		if (c->slots[s].submitted && !c->slots[s].complete) { int rc = slot_wait(c, s); if (rc) return rc; }
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return resolve_times(c, true);
+}
+
+extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                                   uint32_t n_reads, uint32_t stride) {
+	if (!c || !p || si < 0 || si >= BWB_MAX_SLOTS || (n_reads && (!reads_fwd || !lens)) || stride == 0) return fail(BWB_E_ARG, "slot_upload: bad argument");
+	int nb = 0;
+	int rc = check_params(p, &nb);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(c->device));
+	Slot &s = c->slots[si];
+	if (s.submitted && !s.complete) { rc = slot_wait(c, si); if (rc) return rc; } /* the slot is being reused */
+	/* every slot in flight runs under the same parameters (they are launch arguments) */
+	if (c->have_params && memcmp(&c->p, p, sizeof(*p)) != 0 && (any_in_flight(c) || c->parked)) { rc = bwb_hip_flush(c); if (rc) return rc; }
+	const bool wide = p->max_gapo > 1;
+	if (c->cls[0].ready && wide != c->wide && c->parked) { rc = bwb_hip_flush(c); if (rc) return rc; }
+	c->p = *p; c->have_params = true;
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,
 	                 p->seed_length, p->max_diff_seed, p->max_best, p->no_indel_length, nb, p->use_precalc ? 1 : 0, p->is_multiref ? 1 : 0 };
-	c->n_reads = n_reads; c->stride = stride; c->maxlen = maxlen;
-	c->wide = p->max_gapo > 1;
+	c->wide = wide;
+
+	/* Reads the kernels cannot represent (longer than 255 bases: aln_entry_t.i is 8-bit, align.h:104; shorter than 12 with -P:
+	 * read2index, align.c:174-186, reads before the buffer) get an empty record and a warning instead of failing the batch. */
+	uint32_t maxlen = 0, n_bad = 0;
+	for (uint32_t i = 0; i < n_reads; i++) {
+		const bool bad = lens[i] > 255 || lens[i] > stride || (p->use_precalc && lens[i] < PRECALC_LEN);
+		if (bad) n_bad++; else maxlen = std::max<uint32_t>(maxlen, lens[i]);
+	}
+	if (n_bad) fprintf(stderr, "[bwbble_hip] warning: %u read(s) longer than 255 bases%s get an empty alignment record\n", n_bad, p->use_precalc ? " or shorter than 12 (-P)" : "");
+	s.n_reads = n_reads; s.stride = std::min<uint32_t>(stride, std::max<uint32_t>(maxlen, 1)); s.maxlen = maxlen;
 	/* per read: an 8-byte record {D pair, D_seed pair, base} for i = 0..maxlen+1, then 16 bytes (work, N count) */
-	c->dstride = 8 * (maxlen + 2) + 16;
+	s.dstride = 8 * (maxlen + 2) + 16;
 	const size_t nr = n_reads ? n_reads : 1;
-	if (nr > c->cap_reads || nr * stride > c->cap_readbytes || nr * c->dstride > c->cap_dbuf) {
-		free_batch(c);
-		c->cap_reads = nr; c->cap_readbytes = nr * stride; c->cap_dbuf = nr * c->dstride;
-		HIPCHK(hipMalloc(&c->d_reads, c->cap_readbytes));
-		HIPCHK(hipMalloc(&c->d_lens, nr * 2));
-		HIPCHK(hipMalloc(&c->d_dbuf, c->cap_dbuf));
-		HIPCHK(hipMalloc(&c->d_status, nr));
-		HIPCHK(hipMalloc(&c->d_worklist, nr * 4));
-		HIPCHK(hipMalloc(&c->d_n, nr * 4));
-		HIPCHK(hipMalloc(&c->d_off, nr * 8));
-		HIPCHK(hipMalloc(&c->d_dstoff, nr * 8));
-	}
+	HIPCHK(s.d_reads.reserve(nr * s.stride));
+	HIPCHK(s.d_lens.reserve(nr * 2));
+	HIPCHK(s.d_dbuf.reserve(nr * s.dstride));
+	HIPCHK(s.d_status.reserve(nr));
+	HIPCHK(s.d_worklist.reserve(nr * 4));
+	HIPCHK(s.d_n.reserve(nr * 4));
+	HIPCHK(s.d_off.reserve(nr * 8));
+	HIPCHK(s.d_ctl.reserve(256));
+	HIPCHK(s.h_ctl.reserve(256));
+	HIPCHK(s.ev_up.create());
+	const uint64_t want = std::max<uint64_t>((uint64_t)nr * 8, 1u << 16); /* hit log: 8 records per read, grown on demand */
+	if (s.log_cap < want) { HIPCHK(s.d_log.alloc(want * 32)); s.log_cap = want; }
+	if (c->dbg_iters) { HIPCHK(s.d_dbg_iters.reserve(nr * 4)); HIPCHK(hipMemsetAsync(s.d_dbg_iters.p, 0, nr * 4, c->cstream)); }
+	/* staging: the caller's buffers are free again when this returns; the copy to HBM proceeds on the copy stream */
+	HIPCHK(s.h_reads.reserve(nr * s.stride));
+	HIPCHK(s.h_lens.reserve(nr * 2));
+	uint8_t *hr = s.h_reads.as<uint8_t>();
+	uint16_t *hl = s.h_lens.as<uint16_t>();
+	if (s.stride == stride && !n_bad) { memcpy(hr, reads_fwd, (size_t)n_reads * stride); memcpy(hl, lens, (size_t)n_reads * 2); }
+	else
+		for (uint32_t i = 0; i < n_reads; i++) {
+			const bool bad = lens[i] > 255 || lens[i] > stride || (p->use_precalc && lens[i] < PRECALC_LEN);
+			hl[i] = bad ? 0 : lens[i];
+			memcpy(hr + (size_t)i * s.stride, reads_fwd + (size_t)i * stride, bad ? 0 : lens[i]);
+		}
 	if (n_reads) {
-		HIPCHK(hipMemcpyAsync(c->d_reads, reads_fwd, (size_t)n_reads * stride, hipMemcpyHostToDevice, c->stream));
-		HIPCHK(hipMemcpyAsync(c->d_lens, lens, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(s.d_reads.p, hr, (size_t)n_reads * s.stride, hipMemcpyHostToDevice, c->cstream));
+		HIPCHK(hipMemcpyAsync(s.d_lens.p, hl, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->cstream));
 	}
-	DBG_T("upload: batch buffers + copies");
-	/* hit log: start at 8 records per read, grown on demand */
-	const uint64_t want = std::max<uint64_t>((uint64_t)nr * 8, 1u << 16);
-	if (c->log_cap < want) {
-		hipFree(c->d_log);
-		c->d_log = nullptr;
-		HIPCHK(hipMalloc(&c->d_log, want * 32));
-		c->log_cap = want;
-	}
-	if (getenv("BWB_DEBUG_ITERS")) { hipFree(c->d_dbg_iters); c->d_dbg_iters = nullptr; HIPCHK(hipMalloc(&c->d_dbg_iters, nr * 4)); HIPCHK(hipMemset(c->d_dbg_iters, 0, nr * 4)); }
-	DBG_T("upload: hit log");
-	int rc = ensure_class(c, 0);
-	if (rc) return rc;
-	DBG_T("upload: ensure_class (pool + scratch)");
-	HIPCHK(hipStreamSynchronize(c->stream));
-	c->uploaded = true; c->ran = false;
-	return BWB_OK;
+	/* the slot's entry of the device table */
+	SlotDesc &d = c->h_descs[si];
+	d.b.reads = s.d_reads.as<uint8_t>(); d.b.lens = s.d_lens.as<uint16_t>(); d.b.n_reads = n_reads; d.b.stride = s.stride;
+	d.b.dbuf = s.d_dbuf.as<uint8_t>(); d.b.dstride = s.dstride; d.b.status = s.d_status.as<uint8_t>(); d.b.dbg_iters = s.d_dbg_iters.as<uint32_t>();
+	d.out.alns = s.d_log.as<uint4>(); d.out.count = s.ctl_count(); d.out.cap = s.log_cap; d.out.off = s.d_off.as<uint64_t>(); d.out.n = s.d_n.as<uint32_t>();
+	d.done = s.ctl_done();
+	/* (pageable source: the runtime stages it before returning, so h_descs may change again right away) */
+	HIPCHK(hipMemcpyAsync(c->d_descs.as<SlotDesc>() + si, &d, sizeof(SlotDesc), hipMemcpyHostToDevice, c->cstream));
+	HIPCHK(hipEventRecord(s.ev_up.e, c->cstream));
+	s.uploaded = true; s.submitted = false; s.complete = false; s.fetched = false;
+	return ensure_class(c, 0);
 }
 
-static Batch make_batch(bwb_hip_ctx *c, const uint32_t *worklist, uint32_t n_work) {
-	Batch b;
-	b.reads = c->d_reads; b.lens = c->d_lens; b.n_reads = c->n_reads; b.stride = c->stride;
-	b.dbuf = c->d_dbuf; b.dstride = c->dstride;
-	b.worklist = worklist; b.n_work = n_work; b.counter = c->d_counter; b.status = c->d_status;
-	b.dbg_iters = c->d_dbg_iters;
-	b.iter_budget = 0; b.lane_stride = 1;
-	return b;
-}
-
-/* reads whose status == want -> device worklist; returns count */
-static int collect(bwb_hip_ctx *c, uint8_t want, std::vector<uint32_t> &ids) {
-	c->h_status.resize(c->n_reads);
-	HIPCHK(hipMemcpy(c->h_status.data(), c->d_status, c->n_reads, hipMemcpyDeviceToHost));
-	ids.clear();
-	for (uint32_t i = 0; i < c->n_reads; i++) if (c->h_status[i] == want) ids.push_back(i);
-	if (!ids.empty()) HIPCHK(hipMemcpy(c->d_worklist, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
-	return BWB_OK;
-}
-
-static int launch_calc_d(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work, int32_t *dbgD, int32_t *dbgDs) {
-	ScratchClass &s = c->cls[k];
-	Batch b = make_batch(c, wl, n_work);
-	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
-	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_calcd) : s.blocks;
+static int launch_calc_d(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint32_t n_work, uint32_t *counter, int32_t *dbgD, int32_t *dbgDs) {
+	ScratchClass &sc = c->cls[k];
+	Slot &s = c->slots[si];
+	Work wk{ wl, n_work, counter, (uint32_t)si, 0, 0, 0 };
+	HIPCHK(hipMemsetAsync(counter, 0, 4, c->stream));
+	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_calcd) : sc.blocks;
 	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
 	const size_t lds = lane_lds(c);
-	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	hipEvent_t e0 = get_event(c), e1 = get_event(c);
+	if (!e0 || !e1) return fail(BWB_E_HIP, "hipEventCreate failed");
+	c->pending.push_back(PendingTime{ e0, e1, 0 });
+	HIPCHK(hipEventRecord(e0, c->stream));
 	if (c->pos32)
-		hipLaunchKernelGGL(kl_calc_d<uint32_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, dbgD, dbgDs,
-		                   c->maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats);
+		hipLaunchKernelGGL(kl_calc_d<uint32_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
+		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>());
 	else
-		hipLaunchKernelGGL(kl_calc_d<uint64_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, dbgD, dbgDs,
-		                   c->maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats);
+		hipLaunchKernelGGL(kl_calc_d<uint64_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
+		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>());
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(c->ev1, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	float ms = 0;
-	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-	c->stats.ms_calc_d += ms; c->stats.launches_calc_d++;
-	if (getenv("BWB_DEBUG")) fprintf(stderr, "[bwb] k_calc_d class %d: %u reads, grid %u, %.3f ms\n", k, n_work, grid, ms);
-	return BWB_OK;
-}
-
-static int run_calc_d(bwb_hip_ctx *c, int32_t *dbgD, int32_t *dbgDs) {
-	int rc = launch_calc_d(c, 0, nullptr, c->n_reads, dbgD, dbgDs);
-	if (rc) return rc;
-	std::vector<uint32_t> ids;
-	for (int k = 1; k <= 2; k++) {
-		rc = collect(c, ST_SCRATCH_OVF, ids);
-		if (rc) return rc;
-		if (ids.empty()) return BWB_OK;
-		c->stats.n_overflow_reads += ids.size();
-		rc = ensure_class(c, k);
-		if (rc) return rc;
-		rc = launch_calc_d(c, k, c->d_worklist, (uint32_t)ids.size(), dbgD, dbgDs);
-		if (rc) return rc;
+	HIPCHK(hipEventRecord(e1, c->stream));
+	if (c->dbg) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+		fprintf(stderr, "[bwb] kl_calc_d class %d slot %d: %u reads, grid %u, %.3f ms\n", k, si, n_work, grid, ms);
 	}
-	rc = collect(c, ST_SCRATCH_OVF, ids);
-	if (rc) return rc;
-	if (!ids.empty()) return fail(BWB_E_OVERFLOW, "calculate_d: SA-interval list exceeded the largest scratch class");
 	return BWB_OK;
 }
 
-static int launch_search(bwb_hip_ctx *c, int k, const uint32_t *wl, uint32_t n_work, uint32_t iter_budget = 0, uint32_t lane_stride = 1) {
+/* one launch of kl_search in class k: new reads come from `wl`/`n_work` of slot si (n_work 0: only parked reads progress) */
+static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint32_t n_work, uint32_t *counter, bool suspend, bool reset_counter = true) {
 	ScratchClass &s = c->cls[k];
-	Batch b = make_batch(c, wl, n_work);
-	b.iter_budget = iter_budget; b.lane_stride = lane_stride;
-	OutBuf ob{ c->d_log, c->d_count, c->log_cap, c->d_off, c->d_n };
+	const bool resume = k == 0 && c->parked;
+	const uint32_t slice_iters = k == 0 ? c->slice_iters : 0;
+	Work wk{ wl, n_work, counter, (uint32_t)si, suspend ? 1u : 0u, slice_iters, resume ? 1u : 0u };
 	const size_t lds = lane_lds(c);
-	HIPCHK(hipMemsetAsync(c->d_counter, 0, 4, c->stream));
-	HIPCHK(hipMemsetAsync(c->d_pool_bump, 0, POOL_REGIONS * 64, c->stream)); /* every launch starts with an empty chunk pool */
-	const uint32_t per_block = LANE_BLOCK / lane_stride;
-	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_search) : s.blocks;
-	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + per_block - 1) / per_block));
+	unsigned int *bump = c->d_pool_bump.as<unsigned int>() + (k == 0 ? 0 : POOL_REGIONS * 16);
+	if (reset_counter) HIPCHK(hipMemsetAsync(counter, 0, 4, c->stream));
+	if (!resume) HIPCHK(hipMemsetAsync(bump, 0, POOL_REGIONS * 64, c->stream)); /* nothing is parked: the launch starts with an empty chunk pool */
+	/* class 0 always runs its full grid: every lane's save word is rewritten by every launch, and the pool geometry
+	 * (regions, private runs) must not change while reads are parked */
+	const uint32_t grid = k == 0 ? (uint32_t)(c->num_cu * c->bpc_search) : std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
+	DevMem &pool = k == 0 ? c->d_pool : c->d_pool2;
+	s.sc.pool = pool.as<uint4>(); s.sc.pool_bump = bump;
 	/* one region per 8 blocks up to POOL_REGIONS, so that the few blocks of a small launch (class 2) are not confined to
 	 * a fraction of the pool; a state word names 2^26 chunks of its region */
-	s.sc.pool = c->d_pool; s.sc.pool_bump = c->d_pool_bump; /* (the pool may have been replaced since the class was set up) */
 	s.sc.n_regions = std::max<uint32_t>(1, std::min<uint32_t>(POOL_REGIONS, grid / 8));
-	s.sc.region_u4 = c->pool_bytes / s.sc.n_regions / 4096 * 256;
+	s.sc.region_u4 = pool.bytes / s.sc.n_regions / 4096 * 256;
 	s.sc.pool_cap = (uint32_t)std::min<size_t>(s.sc.region_u4 * 16 / (c->wide ? 2048 : 1024), (size_t)1 << 26);
 	{ /* private runs take at most three quarters of a region */
 		const uint32_t lanes = (grid + s.sc.n_regions - 1) / s.sc.n_regions * LANE_BLOCK;
 		s.sc.keep = std::min<uint32_t>(c->keep, s.sc.pool_cap / 4 * 3 / lanes);
 	}
-	HIPCHK(hipEventRecord(c->ev0, c->stream));
-	if (c->pos32 && !c->wide)
-		hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
-	else if (c->pos32)
-		hipLaunchKernelGGL((kl_search<uint32_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
-	else if (!c->wide)
-		hipLaunchKernelGGL((kl_search<uint64_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
-	else
-		hipLaunchKernelGGL((kl_search<uint64_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, b, c->kp, s.sc, ob, c->d_stats);
+	hipEvent_t e0 = get_event(c), e1 = get_event(c);
+	if (!e0 || !e1) return fail(BWB_E_HIP, "hipEventCreate failed");
+	c->pending.push_back(PendingTime{ e0, e1, 1 });
+	HIPCHK(hipEventRecord(e0, c->stream));
+	const SlotDesc *descs = c->d_descs.as<SlotDesc>();
+	unsigned long long *st = c->d_stats.as<unsigned long long>();
+	if (c->pos32 && !c->wide) hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
+	else if (c->pos32) hipLaunchKernelGGL((kl_search<uint32_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
+	else if (!c->wide) hipLaunchKernelGGL((kl_search<uint64_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
+	else hipLaunchKernelGGL((kl_search<uint64_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(c->ev1, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	float ms = 0;
-	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-	c->stats.ms_search += ms; c->stats.launches_search++;
-	if (getenv("BWB_DEBUG")) {
-		unsigned int bump[POOL_REGIONS * 16], used_max = 0;
+	HIPCHK(hipEventRecord(e1, c->stream));
+	if (k == 0) {
+		c->parked = suspend || slice_iters != 0;
+		hipEvent_t le = get_event(c);
+		if (!le) return fail(BWB_E_HIP, "hipEventCreate failed");
+		HIPCHK(hipEventRecord(le, c->stream));
+		c->launch_ev.push_back(le);
+		c->n_launches++;
+	}
+	if (c->dbg) {
+		HIPCHK(hipStreamSynchronize(c->stream));
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+		unsigned int hb[POOL_REGIONS * 16], used_max = 0;
 		unsigned long long used = 0;
-		hipMemcpy(bump, c->d_pool_bump, sizeof(bump), hipMemcpyDeviceToHost);
+		int rc = fetch(c, hb, bump, sizeof(hb));
+		if (rc) return rc;
 		const uint32_t priv = (grid + s.sc.n_regions - 1) / s.sc.n_regions * LANE_BLOCK * s.sc.keep;
-		for (uint32_t r = 0; r < s.sc.n_regions; r++) { used += std::min(priv + bump[r * 16], s.sc.pool_cap); used_max = std::max(used_max, priv + bump[r * 16]); }
-		fprintf(stderr, "[bwb] k_search class %d: %u reads, grid %u, budget %u, lane stride %u, %.3f ms, pool chunks used %llu of %d x %u (fullest region asked for %u; %u private per lane)\n", k, n_work, grid, iter_budget, lane_stride, ms, used, (int)s.sc.n_regions, s.sc.pool_cap, used_max, s.sc.keep);
+		for (uint32_t r = 0; r < s.sc.n_regions; r++) { used += std::min(priv + hb[r * 16], s.sc.pool_cap); used_max = std::max(used_max, priv + hb[r * 16]); }
+		fprintf(stderr, "[bwb] kl_search class %d slot %d: %u new reads, grid %u, %s%s, %.3f ms, pool chunks used %llu of %d x %u (fullest region asked for %u; %u private per lane)\n",
+		        k, si, n_work, grid, suspend ? "slice (parks)" : "drains", resume ? ", resumes parked reads" : "", ms, used, (int)s.sc.n_regions, s.sc.pool_cap, used_max, s.sc.keep);
 	}
 	return BWB_OK;
 }
 
-/* grows the hit log if reads were refused for lack of room, then re-runs them in class k */
-static int rerun_out_overflow(bwb_hip_ctx *c, int k) {
-	std::vector<uint32_t> ids;
-	for (int guard = 0; guard < 40; guard++) {
-		int rc = collect(c, ST_OUT_OVF, ids);
-		if (rc) return rc;
-		if (ids.empty()) return BWB_OK;
-		unsigned long long cnt = 0;
-		HIPCHK(hipMemcpy(&cnt, c->d_count, 8, hipMemcpyDeviceToHost));
-		const uint64_t valid = std::min<uint64_t>(cnt, c->log_cap);
-		const uint64_t ncap = c->log_cap * 4;
-		uint4 *nl = nullptr;
-		HIPCHK(hipMalloc(&nl, ncap * 32));
-		HIPCHK(hipMemcpy(nl, c->d_log, valid * 32, hipMemcpyDeviceToDevice));
-		hipFree(c->d_log);
-		c->d_log = nl; c->log_cap = ncap;
-		cnt = valid;
-		HIPCHK(hipMemcpy(c->d_count, &cnt, 8, hipMemcpyHostToDevice));
-		rc = launch_search(c, k, c->d_worklist, (uint32_t)ids.size());
-		if (rc) return rc;
-	}
-	return fail(BWB_E_OVERFLOW, "hit log kept overflowing");
+static int submit(bwb_hip_ctx *c, int si, bool suspend) {
+	Slot &s = c->slots[si];
+	if (!s.uploaded) return fail(BWB_E_STATE, "slot_submit: nothing uploaded into this slot");
+	if (s.submitted && !s.complete) return fail(BWB_E_STATE, "slot_submit: the slot is still in flight");
+	int rc = ensure_class(c, 0);
+	if (rc) return rc;
+	HIPCHK(hipStreamWaitEvent(c->stream, s.ev_up.e, 0));
+	HIPCHK(hipMemsetAsync(s.d_ctl.p, 0, 256, c->stream));
+	s.submitted = true; s.complete = false; s.fetched = false;
+	if (s.n_reads == 0) { s.complete = true; s.launch = c->n_launches; return BWB_OK; }
+	HIPCHK(hipMemsetAsync(s.d_n.p, 0, (size_t)s.n_reads * 4, c->stream));
+	HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_reads, c->stream));
+	rc = launch_calc_d(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), nullptr, nullptr);
+	if (rc) return rc;
+	rc = launch_search(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), suspend);
+	if (rc) return rc;
+	s.launch = c->n_launches;
+	return BWB_OK;
 }
 
-extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
-	if (!c || !c->uploaded) return fail(BWB_E_STATE, "batch_run: no batch uploaded");
+extern "C" int bwb_hip_slot_submit(bwb_hip_ctx *c, int si) {
+	if (!c || si < 0 || si >= BWB_MAX_SLOTS) return fail(BWB_E_ARG, "slot_submit: bad argument");
 	HIPCHK(hipSetDevice(c->device));
-	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 40, c->stream));
-	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
-	if (c->n_reads == 0) { c->ran = true; return BWB_OK; }
-	HIPCHK(hipMemsetAsync(c->d_n, 0, (size_t)c->n_reads * 4, c->stream));
-	hipEvent_t t0, t1;
-	HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
-	HIPCHK(hipEventRecord(t0, c->stream));
-	int rc = run_calc_d(c, nullptr, nullptr);
+	return submit(c, si, true);
+}
+
+/* reads of the slot whose status == want -> the slot's device worklist */
+static int collect(bwb_hip_ctx *c, Slot &s, uint8_t want, std::vector<uint32_t> &ids) {
+	s.h_status.resize(s.n_reads);
+	int rc = fetch(c, s.h_status.data(), s.d_status.p, s.n_reads);
 	if (rc) return rc;
-	/* phase 1: every read, with an iteration budget; phase 2: the reads that exceeded it (the heavy tail),
-	 * restarted together, one per octet, so that each runs the low-latency cooperative path from the start */
-	uint32_t budget = 0; /* off by default: measured slower than one launch (1534 + 770 ms vs 2105 ms, chr21-scale -n 3, 1 M reads) */
-	if (getenv("BWB_ITER_BUDGET")) budget = (uint32_t)strtoul(getenv("BWB_ITER_BUDGET"), nullptr, 10);
-	rc = launch_search(c, 0, nullptr, c->n_reads, budget, 1);
-	if (rc) return rc;
-	std::vector<uint32_t> ids;
-	if (budget) {
-		rc = collect(c, ST_HEAVY, ids);
-		if (rc) return rc;
-		if (!ids.empty()) {
-			c->stats.n_heavy_reads = ids.size();
-			rc = launch_search(c, 0, c->d_worklist, (uint32_t)ids.size(), 0, 8);
-			if (rc) return rc;
-		}
+	ids.clear();
+	for (uint32_t i = 0; i < s.n_reads; i++) if (s.h_status[i] == want) ids.push_back(i);
+	if (!ids.empty()) {
+		HIPCHK(hipMemcpyAsync(s.d_worklist.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
 	}
-	rc = rerun_out_overflow(c, 0);
+	return BWB_OK;
+}
+
+/* grows the slot's hit log (keeping what is in it) */
+static int grow_log(bwb_hip_ctx *c, int si) {
+	Slot &s = c->slots[si];
+	unsigned long long cnt = 0;
+	int rc = fetch(c, &cnt, s.ctl_count(), 8);
 	if (rc) return rc;
+	const uint64_t valid = std::min<uint64_t>(cnt, s.log_cap);
+	const uint64_t ncap = s.log_cap * 4;
+	DevMem nl;
+	HIPCHK(nl.alloc(ncap * 32));
+	HIPCHK(hipMemcpyAsync(nl.p, s.d_log.p, valid * 32, hipMemcpyDeviceToDevice, c->stream));
+	cnt = valid;
+	HIPCHK(hipMemcpyAsync(s.ctl_count(), &cnt, 8, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	std::swap(s.d_log.p, nl.p); std::swap(s.d_log.bytes, nl.bytes);
+	s.log_cap = ncap;
+	c->h_descs[si].out.alns = s.d_log.as<uint4>(); c->h_descs[si].out.cap = ncap;
+	HIPCHK(hipMemcpyAsync(c->d_descs.as<SlotDesc>() + si, &c->h_descs[si], sizeof(SlotDesc), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return BWB_OK;
+}
+
+/* Re-runs, in the larger scratch classes, the reads of a finished slot that did not fit class 0: an SA-interval list or the
+ * hit list overflowed, the chunk pool was empty when the read needed it, or the slot's hit log was full.  Draining launches
+ * on the kernel stream (behind whatever slices are queued there). */
+static int rerun_overflows(bwb_hip_ctx *c, int si) {
+	Slot &s = c->slots[si];
+	std::vector<uint32_t> todo, dids, list;
+	auto load_status = [&]() { s.h_status.resize(s.n_reads); return fetch(c, s.h_status.data(), s.d_status.p, s.n_reads); };
+	auto put_worklist = [&](const std::vector<uint32_t> &v) -> int {
+		HIPCHK(hipMemcpyAsync(s.d_worklist.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		return BWB_OK;
+	};
 	for (int k = 1; k <= 2; k++) {
-		rc = collect(c, ST_SCRATCH_OVF, ids);
+		int rc = load_status();
 		if (rc) return rc;
-		if (ids.empty()) break;
-		c->stats.n_overflow_reads += ids.size();
+		todo.clear(); dids.clear();
+		for (uint32_t i = 0; i < s.n_reads; i++) {
+			if (s.h_status[i] != ST_OK) todo.push_back(i);
+			if (s.h_status[i] == ST_D_OVF) dids.push_back(i);
+		}
+		if (todo.empty()) return BWB_OK;
+		c->stats.n_overflow_reads += todo.size();
 		rc = ensure_class(c, k);
 		if (rc) return rc;
-		rc = launch_search(c, k, c->d_worklist, (uint32_t)ids.size());
-		if (rc) return rc;
-		rc = rerun_out_overflow(c, k);
-		if (rc) return rc;
+		if (!dids.empty()) { /* calculate_d first: it leaves ST_OK, or ST_D_OVF again (then the next class tries) */
+			rc = put_worklist(dids);
+			if (rc) return rc;
+			rc = launch_calc_d(c, k, si, s.d_worklist.as<uint32_t>(), (uint32_t)dids.size(), s.ctl_counter2(), nullptr, nullptr);
+			if (rc) return rc;
+			HIPCHK(hipStreamSynchronize(c->stream));
+			rc = load_status();
+			if (rc) return rc;
+		}
+		list.clear();
+		for (uint32_t i : todo) if (s.h_status[i] != ST_D_OVF) list.push_back(i);
+		for (int guard = 0; !list.empty(); guard++) {
+			if (guard == 40) return fail(BWB_E_OVERFLOW, "hit log kept overflowing");
+			bool out_ovf = false;
+			for (uint32_t i : list) out_ovf |= s.h_status[i] == ST_OUT_OVF;
+			if (out_ovf) { rc = grow_log(c, si); if (rc) return rc; }
+			rc = put_worklist(list);
+			if (rc) return rc;
+			rc = launch_search(c, k, si, s.d_worklist.as<uint32_t>(), (uint32_t)list.size(), s.ctl_counter2(), false);
+			if (rc) return rc;
+			HIPCHK(hipStreamSynchronize(c->stream));
+			rc = load_status();
+			if (rc) return rc;
+			/* only reads the hit log had no room for are repeated within a class (the log grows x4 each time) */
+			std::vector<uint32_t> again;
+			for (uint32_t i : list) if (s.h_status[i] == ST_OUT_OVF) again.push_back(i);
+			list.swap(again);
+		}
 	}
-	rc = collect(c, ST_SCRATCH_OVF, ids);
+	int rc = load_status();
 	if (rc) return rc;
-	if (!ids.empty()) return fail(BWB_E_OVERFLOW, "a read exceeded the largest per-read scratch class");
-	HIPCHK(hipEventRecord(t1, c->stream));
+	for (uint32_t i = 0; i < s.n_reads; i++)
+		if (s.h_status[i] != ST_OK) return fail(BWB_E_OVERFLOW, "a read exceeded the largest per-read scratch class");
+	return BWB_OK;
+}
+
+static int slot_wait(bwb_hip_ctx *c, int si) {
+	Slot &s = c->slots[si];
+	if (!s.submitted) return fail(BWB_E_STATE, "slot_wait: the slot has not been submitted");
+	if (s.complete) return BWB_OK;
+	/* A slice leaves the slot's unfinished reads parked; the slice after it resumes them and normally finishes them long
+	 * before it ends.  So: wait for the slot's own slice; if reads are left, for the next queued one; and when nothing is
+	 * queued any more, launch a draining slice. */
+	uint64_t L = s.launch;
+	for (;;) {
+		HIPCHK(hipEventSynchronize(c->launch_ev[L - 1]));
+		unsigned int done = 0;
+		int rc = fetch(c, &done, s.ctl_done(), 4);
+		if (rc) return rc;
+		if (done >= s.n_reads) break;
+		if (L < c->n_launches) { L++; continue; }
+		/* (the slot's cursor is where the slices left it: normally exhausted, so only parked reads run) */
+		rc = launch_search(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), false, false);
+		if (rc) return rc;
+		L = c->n_launches;
+	}
+	int rc = resolve_times(c, false);
+	if (rc) return rc;
+	/* anything that needs a larger scratch class?  (one byte per read; almost always all zero) */
+	s.h_status.resize(s.n_reads);
+	rc = fetch(c, s.h_status.data(), s.d_status.p, s.n_reads);
+	if (rc) return rc;
+	bool clean = true;
+	for (uint32_t i = 0; i < s.n_reads && clean; i++) clean = s.h_status[i] == ST_OK;
+	if (!clean) { rc = rerun_overflows(c, si); if (rc) return rc; }
+	s.complete = true;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_slot_wait(bwb_hip_ctx *c, int si) {
+	if (!c || si < 0 || si >= BWB_MAX_SLOTS) return fail(BWB_E_ARG, "slot_wait: bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	return slot_wait(c, si);
+}
+
+extern "C" int bwb_hip_slot_result(bwb_hip_ctx *c, int si, bwb_result *out) {
+	if (!c || !out || si < 0 || si >= BWB_MAX_SLOTS) return fail(BWB_E_ARG, "slot_result: bad argument");
+	HIPCHK(hipSetDevice(c->device));
+	Slot &s = c->slots[si];
+	if (!s.submitted) return fail(BWB_E_STATE, "slot_result: the slot has not been submitted");
+	int rc = slot_wait(c, si);
+	if (rc) return rc;
+	const uint32_t n = s.n_reads;
+	if (!s.fetched) {
+		/* per-read counts and offsets into the hit log, and the log itself, on the result stream (the kernel stream keeps running) */
+		unsigned long long cnt = 0;
+		if (n) {
+			HIPCHK(s.h_cnt.reserve((size_t)n * 4));
+			HIPCHK(s.h_off.reserve((size_t)n * 8));
+			HIPCHK(hipMemcpyAsync(s.h_cnt.p, s.d_n.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->rstream));
+			HIPCHK(hipMemcpyAsync(s.h_off.p, s.d_off.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->rstream));
+			HIPCHK(hipMemcpyAsync(s.h_ctl.p, s.ctl_count(), 8, hipMemcpyDeviceToHost, c->rstream));
+			HIPCHK(hipStreamSynchronize(c->rstream));
+			cnt = std::min<unsigned long long>(*s.h_ctl.as<unsigned long long>(), s.log_cap);
+			if (cnt) {
+				HIPCHK(s.h_log.reserve((size_t)cnt * 32));
+				HIPCHK(hipMemcpyAsync(s.h_log.p, s.d_log.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->rstream));
+				HIPCHK(hipStreamSynchronize(c->rstream));
+			}
+		}
+		/* into read order (the log is in completion order; a read's hits are contiguous and in discovery order) */
+		const uint32_t *hc = s.h_cnt.as<uint32_t>();
+		const uint64_t *ho = s.h_off.as<uint64_t>();
+		const bwb_aln *hl = s.h_log.as<bwb_aln>();
+		s.h_aln_off.assign((size_t)n + 1, 0);
+		for (uint32_t i = 0; i < n; i++) s.h_aln_off[i + 1] = s.h_aln_off[i] + hc[i];
+		const uint64_t total = s.h_aln_off[n];
+		s.h_alns.resize(total ? total : 1);
+		for (uint32_t i = 0; i < n; i++) {
+			if (!hc[i]) continue;
+			if (ho[i] + hc[i] > cnt) return fail(BWB_E_STATE, "slot_result: a read's hits lie outside the hit log");
+			memcpy(&s.h_alns[s.h_aln_off[i]], hl + ho[i], (size_t)hc[i] * 32);
+		}
+		s.fetched = true;
+	}
+	out->n_reads = n;
+	out->aln_off = s.h_aln_off.data();
+	out->alns = s.h_alns.data();
+	return BWB_OK;
+}
+
+/* ---- the one-batch interface: slot 0, one draining launch ------------------------------------------------------ */
+extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                                    uint32_t n_reads, uint32_t stride) {
+	if (!c) return fail(BWB_E_ARG, "batch_upload: null context");
+	int rc = bwb_hip_flush(c); /* this interface owns the context: nothing else may be in flight */
+	if (rc) return rc;
+	rc = bwb_hip_slot_upload(c, 0, p, reads_fwd, lens, n_reads, stride);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(c->cstream));
 	HIPCHK(hipStreamSynchronize(c->stream));
-	float ms = 0;
-	HIPCHK(hipEventElapsedTime(&ms, t0, t1));
-	c->stats.ms_total = ms;
-	hipEventDestroy(t0); hipEventDestroy(t1);
-	unsigned long long st[40];
-	HIPCHK(hipMemcpy(st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+	return BWB_OK;
+}
+
+static int read_device_stats(bwb_hip_ctx *c) {
+	unsigned long long st[STAT_WORDS];
+	int rc = fetch(c, st, c->d_stats.p, sizeof(st));
+	if (rc) return rc;
 	c->stats.visits_single = st[STAT_VIS_SINGLE]; c->stats.visits_alphabet = st[STAT_VIS_ALPHA]; c->stats.visits_calc_d = st[STAT_VIS_CALCD];
 	c->stats.heap_pops = st[STAT_POPS]; c->stats.heap_pushes = st[STAT_PUSHES]; c->stats.n_alignments = st[STAT_ALNS];
-	if (getenv("BWB_DEBUG")) {
-		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu, wave iterations %llu (%.1f of 64 lanes busy)\n", st[STAT_N], st[STAT_N_MAX], st[16], st[16] ? (double)st[STAT_N] / (double)st[16] : 0.0);
-		if (st[24 + 3]) {
-			double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[24 + k];
+	c->stats.bucket_loads_search = st[STAT_BKT_SEARCH]; c->stats.bucket_loads_calc_d = st[STAT_BKT_CALCD];
+	c->stats.n_parked_reads = st[STAT_PARKED];
+	c->stats.lane_iterations = st[STAT_N]; c->stats.wave_iterations = st[STAT_WAVE_ITERS];
+	if (c->dbg) {
+		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu, wave iterations %llu (%.1f of 64 lanes busy), reads parked at slice ends %llu\n",
+		        st[STAT_N], st[STAT_N_MAX], st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS] ? (double)st[STAT_N] / (double)st[STAT_WAVE_ITERS] : 0.0, st[STAT_PARKED]);
+		if (st[STAT_STAMPS + 3]) {
+			double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[STAT_STAMPS + k];
 			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E(exact)", "-", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "-", "-" };
 			fprintf(stderr, "[bwb] stamps (%% of lane cycles):");
-			for (int k = 0; k < 16; k++) if (st[24 + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[24 + k] / tot);
+			for (int k = 0; k < 16; k++) if (st[STAT_STAMPS + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[STAT_STAMPS + k] / tot);
 			fprintf(stderr, "\n");
 		}
 	}
-	c->ran = true;
 	return BWB_OK;
 }
 
+extern "C" int bwb_hip_reset_stats(bwb_hip_ctx *c) {
+	if (!c) return fail(BWB_E_ARG, "reset_stats: null context");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = resolve_times(c, false);
+	if (rc) return rc;
+	memset(&c->stats, 0, sizeof(c->stats));
+	HIPCHK(hipMemsetAsync(c->d_stats.p, 0, sizeof(unsigned long long) * STAT_WORDS, c->stream));
+	c->t_run0 = wall_s();
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_batch_run(bwb_hip_ctx *c) {
+	if (!c || !c->slots[0].uploaded) return fail(BWB_E_STATE, "batch_run: no batch uploaded");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = bwb_hip_flush(c);
+	if (rc) return rc;
+	rc = bwb_hip_reset_stats(c);
+	if (rc) return rc;
+	const double t0 = wall_s();
+	rc = submit(c, 0, c->force_slices);
+	if (rc) return rc;
+	rc = slot_wait(c, 0);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->stats.ms_total = (wall_s() - t0) * 1e3;
+	rc = resolve_times(c, true);
+	if (rc) return rc;
+	return read_device_stats(c);
+}
+
+/* totals since the last reset_stats / batch_run; kernel times cover the launches that have finished */
 extern "C" int bwb_hip_get_stats(bwb_hip_ctx *c, bwb_stats *out) {
 	if (!c || !out) return fail(BWB_E_ARG, "get_stats: null argument");
+	HIPCHK(hipSetDevice(c->device));
+	int rc = resolve_times(c, false);
+	if (rc) return rc;
+	rc = read_device_stats(c);
+	if (rc) return rc;
 	*out = c->stats;
 	return BWB_OK;
 }
 
 extern "C" int bwb_hip_batch_result(bwb_hip_ctx *c, bwb_result *out) {
 	if (!c || !out) return fail(BWB_E_ARG, "batch_result: null argument");
-	if (!c->ran) return fail(BWB_E_STATE, "batch_result: batch_run has not completed");
-	HIPCHK(hipSetDevice(c->device));
-	const uint32_t n = c->n_reads;
-	std::vector<uint32_t> cnt(n ? n : 1);
-	if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_n, (size_t)n * 4, hipMemcpyDeviceToHost));
-	c->h_aln_off.assign((size_t)n + 1, 0);
-	for (uint32_t i = 0; i < n; i++) c->h_aln_off[i + 1] = c->h_aln_off[i] + cnt[i];
-	const uint64_t total = c->h_aln_off[n];
-	c->h_alns.resize(total ? total : 1);
-	if (total) {
-		if (c->sorted_cap < total) {
-			hipFree(c->d_sorted); c->d_sorted = nullptr;
-			HIPCHK(hipMalloc(&c->d_sorted, total * 32));
-			c->sorted_cap = total;
-		}
-		HIPCHK(hipMemcpy(c->d_dstoff, c->h_aln_off.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-		hipLaunchKernelGGL(k_gather, dim3((n + 31) / 32), dim3(256), 0, c->stream, c->d_log, c->d_off, c->d_n, c->d_dstoff, n, c->d_sorted);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipStreamSynchronize(c->stream));
-		HIPCHK(hipMemcpy(c->h_alns.data(), c->d_sorted, total * 32, hipMemcpyDeviceToHost));
-	}
-	out->n_reads = n;
-	out->aln_off = c->h_aln_off.data();
-	out->alns = c->h_alns.data();
-	return BWB_OK;
+	if (!c->slots[0].submitted || !c->slots[0].complete) return fail(BWB_E_STATE, "batch_result: batch_run has not completed");
+	return bwb_hip_slot_result(c, 0, out);
 }
 
 extern "C" int bwb_hip_align_batch(bwb_hip_ctx *c, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
                                    uint32_t n_reads, uint32_t stride, bwb_result *out) {
-	const bool dbg = getenv("BWB_DEBUG") != nullptr;
+	if (!c) return fail(BWB_E_ARG, "align_batch: null context");
 	double t0 = wall_s();
 	int rc = bwb_hip_batch_upload(c, p, reads_fwd, lens, n_reads, stride);
 	if (rc) return rc;
@@ -564,29 +868,52 @@ extern "C" int bwb_hip_align_batch(bwb_hip_ctx *c, const bwb_params *p, const ui
 	if (rc) return rc;
 	const double t2 = wall_s();
 	rc = bwb_hip_batch_result(c, out);
-	if (dbg) fprintf(stderr, "[bwb] align_batch: upload %.3f s, run %.3f s, result %.3f s\n", t1 - t0, t2 - t1, wall_s() - t2);
+	if (c->dbg) fprintf(stderr, "[bwb] align_batch: upload %.3f s, run %.3f s, result %.3f s\n", t1 - t0, t2 - t1, wall_s() - t2);
 	return rc;
 }
 
 extern "C" int bwb_hip_calc_d(bwb_hip_ctx *c, int32_t *out_D, int32_t *out_Dseed) {
 	if (!c || !out_D || !out_Dseed) return fail(BWB_E_ARG, "calc_d: null argument");
-	if (!c->uploaded) return fail(BWB_E_STATE, "calc_d: no batch uploaded");
+	Slot &s = c->slots[0];
+	if (!s.uploaded) return fail(BWB_E_STATE, "calc_d: no batch uploaded");
 	HIPCHK(hipSetDevice(c->device));
-	const size_t nD = (size_t)c->n_reads * (c->maxlen + 1) * 2, nS = (size_t)c->n_reads * (c->kp.seed_length + 1) * 2;
-	int32_t *dD = nullptr, *dS = nullptr;
-	HIPCHK(hipMalloc(&dD, (nD ? nD : 1) * 4));
-	HIPCHK(hipMalloc(&dS, (nS ? nS : 1) * 4));
-	HIPCHK(hipMemset(dD, 0, (nD ? nD : 1) * 4));
-	HIPCHK(hipMemset(dS, 0, (nS ? nS : 1) * 4));
-	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 40, c->stream));
-	int rc = c->n_reads ? run_calc_d(c, dD, dS) : BWB_OK;
-	if (!rc) {
-		hipMemcpy(out_D, dD, nD * 4, hipMemcpyDeviceToHost);
-		hipMemcpy(out_Dseed, dS, nS * 4, hipMemcpyDeviceToHost);
+	int rc = bwb_hip_flush(c);
+	if (rc) return rc;
+	const size_t nD = (size_t)s.n_reads * (s.maxlen + 1) * 2, nS = (size_t)s.n_reads * (c->kp.seed_length + 1) * 2;
+	DevMem dD, dS;
+	HIPCHK(dD.alloc((nD ? nD : 1) * 4));
+	HIPCHK(dS.alloc((nS ? nS : 1) * 4));
+	HIPCHK(hipMemsetAsync(dD.p, 0, (nD ? nD : 1) * 4, c->stream));
+	HIPCHK(hipMemsetAsync(dS.p, 0, (nS ? nS : 1) * 4, c->stream));
+	rc = bwb_hip_reset_stats(c);
+	if (rc) return rc;
+	if (s.n_reads) {
+		HIPCHK(hipStreamWaitEvent(c->stream, s.ev_up.e, 0));
+		HIPCHK(hipMemsetAsync(s.d_status.p, 0, s.n_reads, c->stream));
+		rc = launch_calc_d(c, 0, 0, nullptr, s.n_reads, s.ctl_counter(), dD.as<int32_t>(), dS.as<int32_t>());
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(c->stream));
+		std::vector<uint32_t> ids;
+		for (int k = 1; k <= 2; k++) {
+			rc = collect(c, s, ST_D_OVF, ids);
+			if (rc) return rc;
+			if (ids.empty()) break;
+			rc = ensure_class(c, k);
+			if (rc) return rc;
+			rc = launch_calc_d(c, k, 0, s.d_worklist.as<uint32_t>(), (uint32_t)ids.size(), s.ctl_counter2(), dD.as<int32_t>(), dS.as<int32_t>());
+			if (rc) return rc;
+			HIPCHK(hipStreamSynchronize(c->stream));
+		}
+		rc = collect(c, s, ST_D_OVF, ids);
+		if (rc) return rc;
+		if (!ids.empty()) return fail(BWB_E_OVERFLOW, "calculate_d: SA-interval list exceeded the largest scratch class");
 	}
-	hipFree(dD); hipFree(dS);
-	return rc;
+	HIPCHK(hipMemcpyAsync(out_D, dD.p, nD * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(out_Dseed, dS.p, nS * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	rc = resolve_times(c, true);
+	if (rc) return rc;
+	return read_device_stats(c);
 }
 
 extern "C" int bwb_hip_rank16(bwb_hip_ctx *c, const uint64_t *pos, size_t n, int inc, int exact, uint64_t *out) {
@@ -595,86 +922,102 @@ extern "C" int bwb_hip_rank16(bwb_hip_ctx *c, const uint64_t *pos, size_t n, int
 	for (size_t i = 0; i < n; i++)
 		if (pos[i] != ~0ull && pos[i] >= c->ix.length) return fail(BWB_E_ARG, "rank16: position out of range");
 	HIPCHK(hipSetDevice(c->device));
-	uint64_t *dp = nullptr, *dout = nullptr;
-	HIPCHK(hipMalloc(&dp, n * 8));
-	HIPCHK(hipMalloc(&dout, n * 128));
-	HIPCHK(hipMemcpy(dp, pos, n * 8, hipMemcpyHostToDevice));
+	DevMem dp, dout;
+	HIPCHK(dp.alloc(n * 8));
+	HIPCHK(dout.alloc(n * 128));
+	HIPCHK(hipMemcpyAsync(dp.p, pos, n * 8, hipMemcpyHostToDevice, c->stream));
 	const unsigned grid = (unsigned)std::min<size_t>((n + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK, (size_t)c->num_cu * 8);
-	hipLaunchKernelGGL(k_rank16, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, dp, (uint64_t)n, inc, exact, dout);
+	hipLaunchKernelGGL(k_rank16, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, dp.as<uint64_t>(), (uint64_t)n, inc, exact, dout.as<uint64_t>());
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, dout.p, n * 128, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(hipMemcpy(out, dout, n * 128, hipMemcpyDeviceToHost));
-	hipFree(dp); hipFree(dout);
 	return BWB_OK;
 }
 
-extern "C" int bwb_hip_rank_bench(bwb_hip_ctx *c, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum) {
-	if (!c || n == 0 || iters < 1) return fail(BWB_E_ARG, "rank_bench: bad argument");
+/* layout 0: octet-cooperative rank (k_rank_bench); 1: one query per lane, the layout of the alignment kernels */
+static int rank_bench(bwb_hip_ctx *c, int layout, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum) {
+	if (!c || n < 4 || iters < 1) return fail(BWB_E_ARG, "rank_bench: bad argument");
+	n &= ~(size_t)3;
 	HIPCHK(hipSetDevice(c->device));
-	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
+	unsigned long long *cs = c->d_misc.as<unsigned long long>();
+	HIPCHK(hipMemsetAsync(cs, 0, 8, c->stream));
 	const unsigned grid = (unsigned)(c->num_cu * 8);
 	auto launch = [&](uint64_t sd) {
-		if (c->pos32) hipLaunchKernelGGL(k_rank_bench<uint32_t>, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, c->d_count);
-		else hipLaunchKernelGGL(k_rank_bench<uint64_t>, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, c->d_count);
+		if (layout == 0) {
+			if (c->pos32) hipLaunchKernelGGL(k_rank_bench<uint32_t>, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, cs);
+			else hipLaunchKernelGGL(k_rank_bench<uint64_t>, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, cs);
+		} else {
+			if (c->pos32) hipLaunchKernelGGL(k_rank_bench_lane<uint32_t>, dim3(grid), dim3(LANE_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, cs);
+			else hipLaunchKernelGGL(k_rank_bench_lane<uint64_t>, dim3(grid), dim3(LANE_BLOCK), 0, c->stream, c->ix, (uint64_t)n, sd, cs);
+		}
 	};
+	Event e0, e1;
+	HIPCHK(e0.create()); HIPCHK(e1.create());
 	launch(seed); /* warm-up */
-	HIPCHK(hipMemsetAsync(c->d_count, 0, 8, c->stream));
-	HIPCHK(hipEventRecord(c->ev0, c->stream));
+	HIPCHK(hipMemsetAsync(cs, 0, 8, c->stream));
+	HIPCHK(hipEventRecord(e0.e, c->stream));
 	for (int i = 0; i < iters; i++)
 		launch(seed + i);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(c->ev1, c->stream));
+	HIPCHK(hipEventRecord(e1.e, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	float ms = 0;
-	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-	unsigned long long cs = 0;
-	HIPCHK(hipMemcpy(&cs, c->d_count, 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipEventElapsedTime(&ms, e0.e, e1.e));
+	unsigned long long v = 0;
+	int rc = fetch(c, &v, cs, 8);
+	if (rc) return rc;
 	if (ms_per_iter) *ms_per_iter = ms / iters;
-	if (checksum) *checksum = cs;
+	if (checksum) *checksum = v;
 	return BWB_OK;
+}
+extern "C" int bwb_hip_rank_bench(bwb_hip_ctx *c, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum) {
+	return rank_bench(c, 0, n, iters, seed, ms_per_iter, checksum);
+}
+extern "C" int bwb_hip_rank_bench_lane(bwb_hip_ctx *c, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum) {
+	return rank_bench(c, 1, n, iters, seed, ms_per_iter, checksum);
 }
 
 extern "C" int bwb_hip_set_sa(bwb_hip_ctx *c, const uint64_t *SA, uint64_t num_sa) {
 	if (!c || !SA || num_sa != (c->ix.length + 31) / 32) return fail(BWB_E_ARG, "set_sa: bad argument");
 	HIPCHK(hipSetDevice(c->device));
-	hipFree(c->d_SA); c->d_SA = nullptr;
-	HIPCHK(hipMalloc(&c->d_SA, num_sa * 8));
-	HIPCHK(hipMemcpy(c->d_SA, SA, num_sa * 8, hipMemcpyHostToDevice));
+	HIPCHK(c->d_SA.alloc(num_sa * 8));
+	HIPCHK(hipMemcpyAsync(c->d_SA.p, SA, num_sa * 8, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
 	c->num_sa = num_sa;
 	return BWB_OK;
 }
 
 extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, uint64_t *out_pos) {
 	if (!c || (n && (!rows || !out_pos))) return fail(BWB_E_ARG, "locate: null argument");
-	if (!c->d_SA) return fail(BWB_E_STATE, "locate: sampled SA not uploaded (bwb_hip_set_sa)");
+	if (!c->d_SA.p) return fail(BWB_E_STATE, "locate: sampled SA not uploaded (bwb_hip_set_sa)");
 	if (n == 0) return BWB_OK;
 	for (size_t i = 0; i < n; i++) if (rows[i] >= c->ix.length) return fail(BWB_E_ARG, "locate: row out of range");
 	HIPCHK(hipSetDevice(c->device));
-	uint64_t *dr = nullptr, *dout = nullptr;
-	HIPCHK(hipMalloc(&dr, n * 8));
-	HIPCHK(hipMalloc(&dout, n * 8));
-	HIPCHK(hipMemcpy(dr, rows, n * 8, hipMemcpyHostToDevice));
+	DevMem dr, dout;
+	HIPCHK(dr.alloc(n * 8));
+	HIPCHK(dout.alloc(n * 8));
+	HIPCHK(hipMemcpyAsync(dr.p, rows, n * 8, hipMemcpyHostToDevice, c->stream));
 	const unsigned grid = (unsigned)std::min<size_t>((n + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK, (size_t)c->num_cu * 8);
-	hipLaunchKernelGGL(k_locate, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, c->d_SA, c->sa0_index, dr, (uint64_t)n, dout);
+	hipLaunchKernelGGL(k_locate, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, c->d_SA.as<uint64_t>(), c->sa0_index, dr.as<uint64_t>(), (uint64_t)n, dout.as<uint64_t>());
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out_pos, dout.p, n * 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
-	HIPCHK(hipMemcpy(out_pos, dout, n * 8, hipMemcpyDeviceToHost));
-	hipFree(dr); hipFree(dout);
 	return BWB_OK;
 }
 
-/* developer aid (not in include/bwbble_hip.h): per-read loop iteration counts of the last batch_run when BWB_DEBUG_ITERS is set */
+/* developer aid (not in include/bwbble_hip.h): per-read loop iteration counts of slot 0 when BWB_DEBUG_ITERS is set */
 extern "C" int bwb_hip_debug_iters(bwb_hip_ctx *c, uint32_t *out) {
-	if (!c || !c->d_dbg_iters) return fail(BWB_E_STATE, "debug iteration counts are off (set BWB_DEBUG_ITERS)");
-	HIPCHK(hipMemcpy(out, c->d_dbg_iters, (size_t)c->n_reads * 4, hipMemcpyDeviceToHost));
-	return BWB_OK;
+	if (!c || !c->slots[0].d_dbg_iters.p) return fail(BWB_E_STATE, "debug iteration counts are off (set BWB_DEBUG_ITERS)");
+	return fetch(c, out, c->slots[0].d_dbg_iters.p, (size_t)c->slots[0].n_reads * 4);
 }
 
-/* developer aid: k_calc_d visits per read of the last batch_run */
+/* developer aid: kl_calc_d visits per read of slot 0 */
 extern "C" int bwb_hip_debug_calcd_work(bwb_hip_ctx *c, uint32_t *out) {
-	if (!c || !c->uploaded) return fail(BWB_E_STATE, "no batch");
-	std::vector<uint8_t> h((size_t)c->n_reads * c->dstride);
-	HIPCHK(hipMemcpy(h.data(), c->d_dbuf, h.size(), hipMemcpyDeviceToHost));
-	for (uint32_t i = 0; i < c->n_reads; i++) memcpy(&out[i], &h[(size_t)i * c->dstride + c->dstride - 8], 4);
+	if (!c || !c->slots[0].uploaded) return fail(BWB_E_STATE, "no batch");
+	Slot &s = c->slots[0];
+	std::vector<uint8_t> h((size_t)s.n_reads * s.dstride);
+	int rc = fetch(c, h.data(), s.d_dbuf.p, h.size());
+	if (rc) return rc;
+	for (uint32_t i = 0; i < s.n_reads; i++) memcpy(&out[i], &h[(size_t)i * s.dstride + s.dstride - 8], 4);
 	return BWB_OK;
 }

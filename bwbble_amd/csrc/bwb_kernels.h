@@ -16,8 +16,8 @@
 #define NONE32 0xFFFFFFFFu
 #define ST_OK 0
 #define ST_SCRATCH_OVF 1  /* heap arena / interval list / hit list too small: re-run in a bigger class */
-#define ST_OUT_OVF 2      /* global hit buffer full: host grows it and re-runs the read */
-#define ST_HEAVY 3        /* exceeded the phase-1 iteration budget: restarted in the heavy-read pass */
+#define ST_OUT_OVF 2      /* the slot's hit log is full: host grows it and re-runs the read */
+#define ST_D_OVF 3        /* kl_calc_d: SA-interval list too small; kl_search leaves the read to the re-run of both kernels in a bigger class */
 
 struct KParams {
 	int max_diff, max_gapo, max_gape, max_entries;
@@ -28,6 +28,7 @@ struct KParams {
 	int multiref;   /* 0: single-genome mode (-S): 4-letter children A,G,C,T in rows 1..4, 1-to-1 exact matching */
 };
 
+/* one resident batch of reads (a "slot" of the context): inputs, what kl_calc_d hands to kl_search, per-read status */
 struct Batch {
 	const uint8_t *reads;     /* [n][stride] read->seq codes */
 	const uint16_t *lens;
@@ -35,24 +36,41 @@ struct Batch {
 	uint8_t *dbuf;            /* [n][dstride]: one 8-byte record per read position i: u16 {D[i-1],D[i-2]}, u16 {Dseed[si-1],Dseed[si-2]}, u8 seq[len-i];
 	                             then the read's N count (dstride-4) and its calculate_d work (dstride-8) */
 	uint32_t dstride;
-	const uint32_t *worklist; /* read ids to process (NULL = 0..n_work-1) */
-	uint32_t n_work;
-	uint32_t *counter;        /* work-stealing cursor */
 	uint8_t *status;          /* per read */
-	uint32_t *dbg_iters;      /* optional (BWB_DEBUG): loop iterations spent on each read */
-	uint32_t iter_budget;     /* k_search: a read that needs more loop iterations than this is parked as ST_HEAVY (0 = unlimited) */
-	uint32_t lane_stride;     /* k_search: only lanes with lane % lane_stride == 0 take reads (8 => one read per octet: cooperative rank) */
+	uint32_t *dbg_iters;      /* optional (BWB_DEBUG_ITERS): loop iterations spent on each read */
 };
 
 struct OutBuf {
-	uint4 *alns;              /* global hit log, 32 B records */
+	uint4 *alns;              /* the slot's hit log, 32 B records */
 	unsigned long long *count;
 	uint64_t cap;
 	uint64_t *off;            /* per read: first record */
 	uint32_t *n;              /* per read: #records */
 };
 
-enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N, STAT_N_MAX, STAT_VIS_CALCD };
+/* what kl_search needs to know about a slot: several slots are alive at once, because a read that is parked at the end of
+ * a slice (see Work) belongs to an earlier batch than the reads the next slice starts */
+struct SlotDesc {
+	Batch b;
+	OutBuf out;
+	unsigned int *done;       /* reads of the slot that have been finished by kl_search (any status) */
+};
+
+/* the work of one launch */
+struct Work {
+	const uint32_t *worklist; /* read ids to process (NULL = 0..n_work-1) */
+	uint32_t n_work;
+	uint32_t *counter;        /* work-stealing cursor */
+	uint32_t slot;            /* the slot those reads belong to */
+	uint32_t suspend;         /* kl_search: when the cursor runs out a wave parks the reads it is working on in the lanes' save
+	                             area and leaves (the next launch resumes them) instead of draining with ever fewer busy lanes */
+	uint32_t slice_iters;     /* kl_search, test knob: park after this many loop iterations of a wave as well (0 = off) */
+	uint32_t resume;          /* kl_search: lanes look for a parked read in their save area first */
+};
+
+enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N, STAT_N_MAX, STAT_VIS_CALCD,
+       STAT_BKT_SEARCH /* 128-byte buckets fetched by kl_search */, STAT_BKT_CALCD, STAT_PARKED /* reads parked at the end of a slice */,
+       STAT_WAVE_ITERS = 16, STAT_STAMPS = 24, STAT_WORDS = 40 };
 
 template <typename P> struct Intv { P L, U; };
 
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_rank_bench(DevIndex ix, uint64_t 
 		for (int u = 0; u < 4; u++) {
 			P v0, v1;
 			rank_finish<P, false>(rq[u], s_base, ol, lane, v0, v1);
-			acc += (unsigned long long)v0 + 3ull * v1;
+			acc += (ol == 0 ? 0ull : (unsigned long long)v0) + 3ull * v1; /* codes 1..15 (code 0 = '$' is never a child) */
 		}
 	}
 	acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);

@@ -38,6 +38,7 @@ template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define BSTATE_ROW 128          /* bucket states per lane: the score range is at most 128 buckets (bwb_hip_batch_upload) */
 #define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
+#define SAVE_U4 16               /* uint4 per lane in the save area */
 
 struct LaneScratch {
 	uint4 *pool;                /* chunk pool in POOL_REGIONS regions (block b uses region b % n_regions: its XCD's when all 8 are in use):
@@ -49,7 +50,10 @@ struct LaneScratch {
 	uint32_t keep;              /* chunks a lane keeps for itself across reads */
 	uint32_t *bstate;           /* [nslots][128]: a lane's bucket states are contiguous (an expansion touches scores that are
 	                               a few apart: one or two lines instead of one line per bucket) */
-	void *lists;                /* [nslots][2*lcap] Intv<P> */
+	void *lists;                /* [nslots][2*lcap] Intv<P>: kl_search (multi-interval exact tails) */
+	void *lists_d;              /* the same for kl_calc_d, which runs between two slices of kl_search while parked reads keep theirs */
+	uint4 *save;                /* [nslots][SAVE_U4]: a lane's read, parked at the end of a slice (word 0 bit 0 = occupied) */
+	uint32_t *blocksave;        /* [blocks][4]: a block's recycle stack {~head lo, ~head hi, chunks, -} across slices */
 	uint4 *alns;                /* [nslots][acap*2] */
 	uint2 *winfo;               /* [nslots][wstride] */
 	uint32_t nslots, lcap, acap, wstride;
@@ -78,7 +82,7 @@ __device__ __forceinline__ void lane_issue(const uint4 *__restrict__ buckets, P 
 /* both sides of an SA interval: when L-1 and U fall into the same bucket (narrow intervals: most of them) the second
  * gather is skipped and the registers are copied */
 template <typename P>
-__device__ __forceinline__ void lane_issue_pair(const uint4 *__restrict__ buckets, P last_row, P pL, P pU, LaneReq<P> &ra, LaneReq<P> &rb) {
+__device__ __forceinline__ uint32_t lane_issue_pair(const uint4 *__restrict__ buckets, P last_row, P pL, P pU, LaneReq<P> &ra, LaneReq<P> &rb) {
 	lane_issue<P>(buckets, last_row, pL, ra);
 	rb.pos = pU;
 	const bool neg = (pU == (P)~(P)0), end = (pU == last_row);
@@ -96,6 +100,7 @@ __device__ __forceinline__ void lane_issue_pair(const uint4 *__restrict__ bucket
 	}
 #pragma unroll
 	for (int k = 0; k < 8; k++) rb.d[k] = t[k];
+	return (ra.regular ? 1u : 0u) + ((rb.regular && !same) ? 1u : 0u); /* 128-byte buckets actually fetched */
 }
 
 /* pop[j] = #j in the bucket's block at offsets [0, pos & 127], j = 1..15 */
@@ -231,17 +236,17 @@ template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, P L,
 	l.tL = L; l.tU = U; l.T++;
 }
 
-__device__ __forceinline__ uint32_t grab_read(const Batch &b) {
-	const uint32_t w = atomicAdd(b.counter, 1u); /* the compiler folds this into one atomic per wave */
-	if (w >= b.n_work) return NONE32;
-	return b.worklist ? b.worklist[w] : w;
+__device__ __forceinline__ uint32_t grab_read(const Work &wk) {
+	const uint32_t w = atomicAdd(wk.counter, 1u); /* the compiler folds this into one atomic per wave */
+	if (w >= wk.n_work) return NONE32;
+	return wk.worklist ? wk.worklist[w] : w;
 }
 
 /* ============================================================================================
  * k_calc_d (one read per lane)
  * ========================================================================================== */
 template <typename P>
-__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
+__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b, Work wk, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
                                                         uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 	load_base<P>(s_base, ix);
 	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
-	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
+	Intv<P> *lbase = (Intv<P> *)sc.lists_d + (size_t)slot * 2 * sc.lcap;
 	const int cap = (int)sc.lcap;
 	const uint4 *__restrict__ buckets = ix.buckets;
 	const P last_row = (P)(ix.length - 1);
@@ -262,12 +267,12 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 	int32_t nm = 0, prev_nm = 0;
 	uint32_t prev_byte = 0, cntN = 0;
 	unsigned long long vis = 0;
-	uint32_t r_vis = 0;
+	uint32_t r_vis = 0, n_bkt = 0;
 	const uint8_t *seq = b.reads;
 
 	for (;;) {
 		if (!active && !done) {
-			rid = grab_read(b);
+			rid = grab_read(wk);
 			if (rid == NONE32) done = true;
 			else {
 				len = b.lens[rid];
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			if (s == curT - 1) { iL = cL; iU = cU; }
 			else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
 			LaneReq<P> ra, rb;
-			lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
+			n_bkt += lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
 			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
 			uint32_t ne = lane_children<P>(ra, rb, s_base, false, kidL, kidU);
 			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			}
 			s++;
 		}
-		if (ovf) { b.status[rid] = ST_SCRATCH_OVF; active = false; continue; }
+		if (ovf) { b.status[rid] = ST_D_OVF; active = false; continue; }
 		if (c > 3 || s >= curT) {
 			/* position finished: swap lists (inexact_match.c:234-237) */
 			cursel ^= 1;
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 		}
 	}
 	if (vis) { atomicAdd(&stats[STAT_VIS_SINGLE], vis); atomicAdd(&stats[STAT_VIS_CALCD], vis); }
+	if (n_bkt) atomicAdd(&stats[STAT_BKT_CALCD], (unsigned long long)n_bkt);
 }
 
 /* ============================================================================================
@@ -521,14 +527,26 @@ template <typename P, bool WIDE> struct LHeap {
 #define STAMP(k) do { } while (0)
 #endif
 
+/* Slices.  One launch of kl_search = one slice of the stream of batches.  Per-read work is heavy-tailed, so a
+ * launch that runs until its last read is done ends with ever fewer busy lanes.  Instead, when the cursor of the batch runs
+ * out (wk.suspend) a wave whose lane could not get a new read PARKS the reads its other lanes are working on - every
+ * register of the per-lane state machine goes to the lane's save area, the heap, lists and hits are in the lane's global
+ * scratch anyway - and leaves; the next launch (which starts the next batch) resumes them in the same lanes.  A parked read
+ * belongs to an earlier slot than the reads its wave starts next, hence the per-lane `myslot` and the slot table. */
 template <typename P, bool WIDE>
-__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b, KParams kp, LaneScratch sc, OutBuf out, unsigned long long *stats) {
+__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
 	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
 	__shared__ unsigned long long s_blockfree;
-	__shared__ unsigned int s_active, s_nfree; /* reads in flight in this block; chunks on its recycle stack */
-	if (threadIdx.x == 0) { s_blockfree = ~0ull; s_active = 0; s_nfree = 0; }
+	__shared__ unsigned int s_active, s_nfree, s_left; /* reads in flight in this block; chunks on its recycle stack; waves that have left */
+	if (threadIdx.x == 0) {
+		const uint32_t *bs = sc.blocksave + (size_t)blockIdx.x * 4;
+		const bool keep = wk.resume != 0;
+		s_blockfree = keep ? ~(((unsigned long long)bs[1] << 32) | bs[0]) : ~0ull;
+		s_nfree = keep ? bs[2] : 0u;
+		s_active = 0; s_left = 0;
+	}
 	load_base<P>(s_base, ix);
 	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
@@ -547,10 +565,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slot * BSTATE_ROW; h.nslots = sc.nslots;
 	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
-	for (int k = 0; k < nb; k++) h.bstate[k] = NONE32;
 
-	bool active = false, done = (threadIdx.x % b.lane_stride) != 0; /* helper-only lanes in the heavy-read pass */
-	uint32_t rid = 0;
+	bool active = false, done = false;
+	uint32_t rid = 0, myslot = wk.slot;
 	int len = 0, mode = LMODE_POP;
 	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
 	int r = 0, s = 0, curT = 0, cursel = 0, r_stop = 0;     /* exact-tail state; it ends after rc[r_stop] */
@@ -561,14 +578,47 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 	int e_score = 0;
-	const uint2 *recs = (const uint2 *)b.dbuf; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
+	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
 	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed only when the read completes */
 	unsigned long long n_iter = 0, w_iter = 0;
-	uint32_t r_iter = 0;
+	uint32_t r_iter = 0, n_bkt = 0, n_parked = 0;
+	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
 #endif
+	uint4 *const mysave = sc.save + (size_t)slot * SAVE_U4;
+	if (wk.resume && (mysave[0].x & 1u)) {
+		/* ---- resume the read this lane parked at the end of the previous slice ---- */
+		const uint4 a0 = mysave[0], a1 = mysave[1], a2 = mysave[2], a3 = mysave[3], a4 = mysave[4], a5 = mysave[5], a6 = mysave[6],
+		            a7 = mysave[7], a8 = mysave[8], a9 = mysave[9], a10 = mysave[10], a11 = mysave[11], a12 = mysave[12], a13 = mysave[13];
+		auto p64 = [](uint32_t lo, uint32_t hi) { return (P)(((uint64_t)hi << 32) | lo); };
+		const uint32_t fl = a0.x;
+		mode = (fl >> 1) & 1u; cursel = (fl >> 2) & 1u; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
+		myslot = (fl >> 8) & 0xFFu;
+		nx.buf = lbase + ((fl >> 6) & 1u) * lcap;
+		rid = a0.y;
+		len = (int)(a0.z & 255u); best_score = (int)((a0.z >> 8) & 255u); max_diff = (int)((a0.z >> 16) & 255u); e_score = (int)(a0.z >> 24);
+		num_best = (int)a0.w;
+		n_alns = (int)a1.x; r = (int)a1.y; s = (int)a1.z; curT = (int)a1.w;
+		r_stop = (int)a2.x; nx.T = (int)a2.y; cL = p64(a2.z, a2.w);
+		cU = p64(a3.x, a3.y); nx.tL = p64(a3.z, a3.w);
+		nx.tU = p64(a4.x, a4.y); nxi.L = p64(a4.z, a4.w);
+		nxi.U = p64(a5.x, a5.y); e.L = p64(a5.z, a5.w);
+		e.U = p64(a6.x, a6.y); e.f = a6.z; e.sa = a6.w;
+		e.runsLo = a7.x; e.runsHi = a7.y; h.fhead = a7.z; h.fnext = a7.w;
+		h.pused = a8.x; h.xhead = a8.y; h.xtail = a8.z; h.xcnt = a8.w;
+		h.neLo = ((uint64_t)a9.y << 32) | a9.x; h.neHi = ((uint64_t)a9.w << 32) | a9.z;
+		h.cb = (int)a10.x; h.cst = a10.y; h.num_entries = (int)a10.z; h.top.f = a10.w;
+		h.top.L = p64(a11.x, a11.y); h.top.U = p64(a11.z, a11.w);
+		h.top.sa = a12.x; h.top.runsLo = a12.y; h.top.runsHi = a12.z; r_vis_s = a12.w;
+		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z; r_iter = a13.w;
+		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
+		active = true;
+		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	} else {
+		for (int k = 0; k < nb; k++) h.bstate[k] = NONE32;
+	}
 
 	for (;;) {
 		STAMP(7);
@@ -586,10 +636,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				admit = avail >= ADMIT_CHUNKS * (mine + 1) || s_active + mine < 4;
 			}
 		}
+		bool park = false;
 		if (admit) {
-			rid = grab_read(b);
-			if (rid == NONE32) done = true;
+			rid = grab_read(wk);
+			if (rid == NONE32) { if (wk.suspend) park = true; else done = true; }
 			else {
+				const Batch &b = descs[wk.slot].b;
+				myslot = wk.slot;
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				r_vis_s = r_vis_a = r_pop = r_push = 0; r_iter = 0;
 				len = b.lens[rid];
@@ -599,7 +652,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
 				n_alns = 0; mode = LMODE_POP; active = true;
 				bool ovf0 = false;
-				bool skip = cntN > kp.max_diff || len == 0; /* inexact_match.c:260-266 */
+				/* a read whose calculate_d overflowed its scratch class waits for the re-run of both kernels in a larger class */
+				const bool dfail = b.status[rid] == ST_D_OVF;
+				bool skip = cntN > kp.max_diff || len == 0 || dfail; /* inexact_match.c:260-266 */
 				seeding = false; r_stop = 0;
 				if (kp.use_precalc && !skip) {
 					/* -P.  A read with an N in the last 12 bases of rc (= the first 12 of seq) gets an empty record
@@ -623,8 +678,41 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				}
 				best_score = kp.num_buckets; /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
 				max_diff = kp.max_diff; num_best = 0;
-				if (ovf0) { b.status[rid] = ST_SCRATCH_OVF; out.n[rid] = 0; h.release_excess(); active = false; __hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+				if (ovf0 || dfail) {
+					if (ovf0) b.status[rid] = ST_SCRATCH_OVF;
+					descs[wk.slot].out.n[rid] = 0; h.release_excess(); active = false;
+					__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					atomicAdd(descs[wk.slot].done, 1u);
+				}
 			}
+		}
+		if (wk.slice_iters && w_iter >= wk.slice_iters) park = true;
+		if (__any(park)) {
+			/* ---- end of the slice for this wave: park the reads under way (word 0 of the save area tells the next launch) ---- */
+			if (active) {
+				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* (lanes of other waves may be waiting for admission) */
+				auto lo = [](P v) { return (uint32_t)v; };
+				auto hi = [](P v) { return (uint32_t)((uint64_t)v >> 32); };
+				const uint32_t fl = 1u | ((uint32_t)mode << 1) | ((uint32_t)cursel << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
+				                    ((h.top_valid ? 1u : 0u) << 5) | ((nx.buf != lbase ? 1u : 0u) << 6) | (myslot << 8);
+				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)best_score << 8) | ((uint32_t)max_diff << 16) | ((uint32_t)e_score << 24), (uint32_t)num_best);
+				mysave[1] = make_uint4((uint32_t)n_alns, (uint32_t)r, (uint32_t)s, (uint32_t)curT);
+				mysave[2] = make_uint4((uint32_t)r_stop, (uint32_t)nx.T, lo(cL), hi(cL));
+				mysave[3] = make_uint4(lo(cU), hi(cU), lo(nx.tL), hi(nx.tL));
+				mysave[4] = make_uint4(lo(nx.tU), hi(nx.tU), lo(nxi.L), hi(nxi.L));
+				mysave[5] = make_uint4(lo(nxi.U), hi(nxi.U), lo(e.L), hi(e.L));
+				mysave[6] = make_uint4(lo(e.U), hi(e.U), e.f, e.sa);
+				mysave[7] = make_uint4(e.runsLo, e.runsHi, h.fhead, h.fnext);
+				mysave[8] = make_uint4(h.pused, h.xhead, h.xtail, h.xcnt);
+				mysave[9] = make_uint4((uint32_t)h.neLo, (uint32_t)(h.neLo >> 32), (uint32_t)h.neHi, (uint32_t)(h.neHi >> 32));
+				mysave[10] = make_uint4((uint32_t)h.cb, h.cst, (uint32_t)h.num_entries, h.top.f);
+				mysave[11] = make_uint4(lo(h.top.L), hi(h.top.L), lo(h.top.U), hi(h.top.U));
+				mysave[12] = make_uint4(h.top.sa, h.top.runsLo, h.top.runsHi, r_vis_s);
+				mysave[13] = make_uint4(r_vis_a, r_pop, r_push, r_iter);
+				n_parked++;
+			}
+			parked = active;
+			break;
 		}
 		if (__all(done)) break;
 		if (!__any(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
@@ -707,7 +795,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 		if (nreq > COOP_MAX_REQ) {
 			if (need_rank) {
 				LaneReq<P> ra, rb;
-				lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
+				n_bkt += lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
 				ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
 			}
 		} else if (nreq > 0) {
@@ -716,6 +804,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, alpha, iL, iU, kids, (int)(threadIdx.x & 63u));
 				for (int t = 0; t < 8; t++) rm &= rm - 1;
 			}
+			n_bkt += (uint32_t)nvis; /* the octet path fetches both buckets of a pair (counted in the owner lane) */
 		}
 		if (!kp.multiref && need_rank) {
 			/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with
@@ -949,22 +1038,23 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 			h.top_valid = true;
 		}
 		STAMP(5);
-		bool heavy = false;
-		if (active && !finish && !ovf && b.iter_budget && r_iter > b.iter_budget) { heavy = true; finish = true; }
 		if (ovf) finish = true;
 		if (finish) {
+			const SlotDesc &d = descs[myslot]; /* (the read may belong to an earlier slot than the one this launch feeds from) */
+			const OutBuf out = d.out;
 			unsigned long long off = 0;
 			bool outovf = false;
-			if (!ovf && !heavy && n_alns > 0) {
+			if (!ovf && n_alns > 0) {
 				off = atomicAdd(out.count, (unsigned long long)n_alns);
 				if (off + (unsigned long long)n_alns > out.cap) outovf = true;
 				else for (int t = 0; t < n_alns * 2; t++) out.alns[off * 2 + t] = myalns[t];
 			}
 			out.off[rid] = off;
-			out.n[rid] = (ovf || outovf || heavy) ? 0u : (uint32_t)n_alns;
-			b.status[rid] = ovf ? ST_SCRATCH_OVF : (heavy ? ST_HEAVY : (outovf ? ST_OUT_OVF : ST_OK));
-			if (b.dbg_iters) b.dbg_iters[rid] = r_iter;
-			if (!ovf && !outovf && !heavy) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
+			out.n[rid] = (ovf || outovf) ? 0u : (uint32_t)n_alns;
+			d.b.status[rid] = ovf ? ST_SCRATCH_OVF : (outovf ? ST_OUT_OVF : ST_OK);
+			if (d.b.dbg_iters) d.b.dbg_iters[rid] = r_iter;
+			if (!ovf && !outovf) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
+			atomicAdd(d.done, 1u);
 			/* leave every bucket state empty for the next read and give its chunks back */
 			h.release_excess();
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -978,10 +1068,52 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, Batch b,
 	if (n_pop) atomicAdd(&stats[STAT_POPS], n_pop);
 	if (n_push) atomicAdd(&stats[STAT_PUSHES], n_push);
 	if (n_aln_tot) atomicAdd(&stats[STAT_ALNS], n_aln_tot);
+	if (n_bkt) atomicAdd(&stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
+	if (n_parked) atomicAdd(&stats[STAT_PARKED], (unsigned long long)n_parked);
 	atomicAdd(&stats[STAT_N], n_iter);        /* debug: total loop iterations */
 	atomicMax(&stats[STAT_N_MAX], n_iter);    /* debug: longest lane */
-	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[16], w_iter); /* debug: wave iterations */
+	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[STAT_WAVE_ITERS], w_iter); /* debug: wave iterations */
 #ifdef BWB_STAMPS
-	if (n_iter) for (int k = 0; k < 16; k++) atomicAdd(&stats[24 + k], seg[k]);
+	if (n_iter) for (int k = 0; k < 16; k++) atomicAdd(&stats[STAT_STAMPS + k], seg[k]);
 #endif
+	if (!parked) mysave[0].x = 0u;
+	/* the last wave of the block to leave hands the block's recycle stack to the next slice */
+	unsigned int left = 0;
+	if ((threadIdx.x & 63u) == 0) left = __hip_atomic_fetch_add((Lds<unsigned int>)&s_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if ((threadIdx.x & 63u) == 0 && left == LANE_BLOCK / 64 - 1) {
+		const unsigned long long v = ~__hip_atomic_load((Lds<unsigned long long>)&s_blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		uint32_t *bs = sc.blocksave + (size_t)blockIdx.x * 4;
+		bs[0] = (uint32_t)v; bs[1] = (uint32_t)(v >> 32); bs[2] = __hip_atomic_load((Lds<unsigned int>)&s_nfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+
+/* Rank micro-benchmark, lane layout: one query per lane (8 x global_load_dwordx4 of one 128-byte bucket, 64 different buckets
+ * per wave instruction), two queries in flight per lane, all 15 codes ranked - the access pattern and the ALU work of a rank
+ * visit in kl_search / kl_calc_d without anything else.  Same queries and same checksum as k_rank_bench (octet layout). */
+template <typename P>
+__global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uint64_t n, uint64_t seed, unsigned long long *checksum) {
+	__shared__ P s_base[BWB_BASE_ROWS * 16];
+	load_base<P>(s_base, ix);
+	const uint64_t nl = (uint64_t)gridDim.x * LANE_BLOCK;
+	const P last_row = (P)(ix.length - 1);
+	unsigned long long acc = 0;
+	for (uint64_t q = ((uint64_t)blockIdx.x * LANE_BLOCK + threadIdx.x) * 2; q < n; q += nl * 2) {
+		LaneReq<P> rq[2];
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			uint64_t x = (q + u) * 0x9E3779B97F4A7C15ull + seed;
+			x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+			lane_issue<P>(ix.buckets, last_row, (P)(x % (ix.length - 1)), rq[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			uint32_t pop[16];
+			lane_pops<P>(rq[u], pop);
+			const P *brow = s_base + rq[u].row * 16;
+#pragma unroll
+			for (int j = 1; j < 16; j++) acc += (unsigned long long)lane_val<P>(rq[u], brow, pop, j) * ((j & 1) ? 3ull : 1ull);
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(checksum, acc);
 }

@@ -2,7 +2,8 @@
 
 The data path has NO collective: the FM-index is replicated per GPU and every rank aligns its own contiguous shard of
 reads (align_reads_inexact_parallel's static chunking, inexact_match.c:115-116, applied across GPUs).  The only
-communication is the timing protocol of the benchmark: barrier, then MAX of the step time and SUM of the work counters.
+communication is the timing protocol of the benchmark (barrier, then MAX of the step time and SUM of the work counters)
+and the exchange of two checksums per rank for the cross-shard parity check.
 """
 import os
 
@@ -48,6 +49,16 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
         return float(t[0]), float(t[1]), float(v[0])
+
+    def all_gather_pairs(self, x, y):
+        """-> [(x_r, y_r) for every rank r] (two integers per rank; used for the cross-shard parity check, not on the data path)."""
+        if self.dist is None:
+            return [(int(x), int(y))]
+        import torch
+        mine = torch.tensor([int(x), int(y)], dtype=torch.int64, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [(int(t[0]), int(t[1])) for t in out]
 
     def close(self):
         if self.dist is not None:

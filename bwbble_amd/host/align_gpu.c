@@ -16,9 +16,10 @@
 #include <unistd.h>
 #include "bwb_host.h"
 
-/* reads per GPU batch (BWB_CHUNK): per-read work is heavy-tailed, so a batch ends with a drain phase in which few lanes
- * are busy; measured at chr21 scale, -n 3: 0.75 M reads/s with 1 M-read batches, 1.19 M reads/s with 4 M-read ones */
-#define GPU_CHUNK_DEFAULT (1u << 22)
+/* reads per GPU batch (BWB_CHUNK).  Batches are streamed as slices that park their unfinished reads for the next slice, so the
+ * size no longer decides how much of the GPU idles at the end of a batch; it trades launch overhead against the balance
+ * between GPUs and the memory of a slot (about 1 KB per read). */
+#define GPU_CHUNK_DEFAULT (1u << 21)
 
 static double wall(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
@@ -30,7 +31,7 @@ typedef struct {
 } chunk_res_t;
 
 typedef struct {
-	int gpu;
+	int gpu, device; /* worker number; HIP device it drives */
 	bwt_t *BWT;
 	reads_t *reads;
 	aln_params_t *params;
@@ -42,40 +43,56 @@ typedef struct {
 	double kernel_ms;
 } worker_t;
 
+/* hands the finished chunk in `slot` to the writer */
+static void retire(worker_t *w, bwb_hip_ctx *ctx, int slot, size_t c) {
+	bwb_result r;
+	if (bwb_hip_slot_result(ctx, slot, &r)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->gpu, bwb_hip_last_error());
+	chunk_res_t *cr = &w->res[c];
+	const uint32_t n = r.n_reads;
+	cr->n = n;
+	cr->aln_off = (uint64_t *)malloc(((size_t)n + 1) * 8);
+	memcpy(cr->aln_off, r.aln_off, ((size_t)n + 1) * 8);
+	const uint64_t tot = r.aln_off[n];
+	cr->alns = (bwb_aln *)malloc((tot ? tot : 1) * sizeof(bwb_aln));
+	memcpy(cr->alns, r.alns, tot * sizeof(bwb_aln));
+	atomic_store(&cr->ready, 1);
+}
+
+/* One host thread per GPU.  Chunks are streamed through three slots of the context: while the search slice of chunk j runs,
+ * chunk j+1 is already uploaded and queued behind it and the hits of chunk j-1 are on their way back; a slice parks its
+ * unfinished reads for the next one instead of draining (include/bwbble_hip.h), so the GPU never runs a batch's tail alone. */
 static void *gpu_worker(void *arg) {
 	worker_t *w = (worker_t *)arg;
 	bwb_hip_ctx *ctx = NULL;
 	const int dbg = getenv("BWB_DEBUG") != NULL;
 	double tq = wall();
 	const bwtint_t hdr[5] = { w->BWT->length, w->BWT->num_words, w->BWT->num_sa, w->BWT->num_occ, w->BWT->sa0_index };
-	if (bwb_hip_ctx_create(w->gpu, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, &ctx)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->gpu, bwb_hip_last_error());
-	if (dbg) { fprintf(stderr, "[bwb host] GPU %d: context + index upload %.3f s\n", w->gpu, wall() - tq); tq = wall(); }
+	if (bwb_hip_ctx_create(w->device, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, &ctx)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+	if (dbg) { fprintf(stderr, "[bwb host] worker %d (device %d): context + index upload %.3f s\n", w->gpu, w->device, wall() - tq); tq = wall(); }
+	enum { NS = 3 };
+	size_t in_slot[NS];
+	size_t j = 0; /* chunks this worker has submitted */
 	for (;;) {
 		const size_t c = atomic_fetch_add(w->cursor, 1);
 		if (c >= w->n_chunks) break;
 		const size_t r0 = c * (size_t)w->chunk;
 		const uint32_t n = (uint32_t)((w->reads->count - r0) < w->chunk ? (w->reads->count - r0) : w->chunk);
-		bwb_result r;
-		if (bwb_hip_align_batch(ctx, w->params, w->reads->seq + r0 * w->reads->stride, w->reads->len + r0, n, w->reads->stride, &r))
-			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->gpu, bwb_hip_last_error());
-		bwb_stats st;
-		bwb_hip_get_stats(ctx, &st);
-		w->total.visits_single += st.visits_single; w->total.visits_alphabet += st.visits_alphabet;
-		w->total.heap_pops += st.heap_pops; w->total.heap_pushes += st.heap_pushes; w->total.n_alignments += st.n_alignments;
-		w->total.n_overflow_reads += st.n_overflow_reads;
-		w->kernel_ms += st.ms_calc_d + st.ms_search;
-		chunk_res_t *cr = &w->res[c];
-		cr->n = n;
-		cr->aln_off = (uint64_t *)malloc(((size_t)n + 1) * 8);
-		memcpy(cr->aln_off, r.aln_off, ((size_t)n + 1) * 8);
-		const uint64_t tot = r.aln_off[n];
-		cr->alns = (bwb_aln *)malloc((tot ? tot : 1) * sizeof(bwb_aln));
-		memcpy(cr->alns, r.alns, tot * sizeof(bwb_aln));
-		atomic_store(&cr->ready, 1);
-		if (dbg) { fprintf(stderr, "[bwb host] GPU %d: chunk %zu (%u reads) %.3f s\n", w->gpu, c, n, wall() - tq); tq = wall(); }
+		const int slot = (int)(j % NS);
+		if (bwb_hip_slot_upload(ctx, slot, w->params, w->reads->seq + r0 * w->reads->stride, w->reads->len + r0, n, w->reads->stride) ||
+		    bwb_hip_slot_submit(ctx, slot))
+			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+		in_slot[slot] = c;
+		j++;
+		if (j >= 3) retire(w, ctx, (int)((j - 3) % NS), in_slot[(j - 3) % NS]); /* two slices stay queued while the host waits */
+		if (dbg) { fprintf(stderr, "[bwb host] worker %d: chunk %zu (%u reads) submitted at +%.3f s\n", w->gpu, c, n, wall() - tq); }
 	}
+	for (size_t k = j >= 2 ? j - 2 : 0; k < j; k++) retire(w, ctx, (int)(k % NS), in_slot[k % NS]);
+	bwb_stats st;
+	if (bwb_hip_flush(ctx) || bwb_hip_get_stats(ctx, &st)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+	w->total = st;
+	w->kernel_ms = st.ms_calc_d + st.ms_search;
 	bwb_hip_ctx_destroy(ctx);
-	if (dbg) fprintf(stderr, "[bwb host] GPU %d: context destroy %.3f s\n", w->gpu, wall() - tq);
+	if (dbg) fprintf(stderr, "[bwb host] worker %d: done %.3f s\n", w->gpu, wall() - tq);
 	return NULL;
 }
 
@@ -86,7 +103,23 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_interva
 	if (!alnFile) { perror(alnFname); bwb_die("align_reads_inexact: Cannot open ALN file: %s!", alnFname); }
 	const int ndev = bwb_hip_device_count();
 	if (ndev < 1) bwb_die("align_reads_inexact_gpu: no HIP device found (this build has no CPU alignment path)");
-	if (n_gpus < 1 || n_gpus > ndev) n_gpus = n_gpus < 1 ? 1 : ndev;
+	/* BWB_DEVICE_MAP=d0,d1,...: worker g drives HIP device d_g (default g).  Several workers on one device are allowed - that
+	 * is how the multi-worker path (shared cursor, ordered writer) is tested on a one-GPU box. */
+	int devmap[64];
+	int nmap = 0;
+	if (getenv("BWB_DEVICE_MAP")) {
+		const char *q = getenv("BWB_DEVICE_MAP");
+		while (*q && nmap < 64) {
+			char *end;
+			const long d = strtol(q, &end, 10);
+			if (end == q) break;
+			if (d < 0 || d >= ndev) bwb_die("align_reads_inexact_gpu: BWB_DEVICE_MAP names device %ld, only %d present", d, ndev);
+			devmap[nmap++] = (int)d;
+			q = *end == ',' ? end + 1 : end;
+		}
+	}
+	if (n_gpus < 1) n_gpus = 1;
+	if (n_gpus > (nmap ? nmap : ndev)) bwb_die("align_reads_inexact_gpu: -g %d asked for, %d HIP device(s) available", n_gpus, nmap ? nmap : ndev);
 	uint32_t chunk = GPU_CHUNK_DEFAULT;
 	if (getenv("BWB_CHUNK")) chunk = (uint32_t)strtoul(getenv("BWB_CHUNK"), NULL, 10);
 	if (chunk < 1) chunk = 1;
@@ -97,7 +130,7 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_interva
 	pthread_t *th = (pthread_t *)calloc((size_t)n_gpus, sizeof(pthread_t));
 	const double t0 = wall();
 	for (int g = 0; g < n_gpus; g++) {
-		ws[g] = (worker_t){ .gpu = g, .BWT = BWT, .reads = reads, .params = params, .chunk = chunk, .n_chunks = n_chunks, .cursor = &cursor, .res = res };
+		ws[g] = (worker_t){ .gpu = g, .device = nmap ? devmap[g] : g, .BWT = BWT, .reads = reads, .params = params, .chunk = chunk, .n_chunks = n_chunks, .cursor = &cursor, .res = res };
 		if (pthread_create(&th[g], NULL, gpu_worker, &ws[g])) bwb_die("align_reads_inexact_gpu: cannot start a host thread");
 	}
 	/* ordered writer (the reference writes after each batch, inexact_match.c:154-162) */

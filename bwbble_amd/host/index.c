@@ -7,9 +7,12 @@
  * five characters (20-bit radix, counting sort) and every bucket is refined by sorting 16-character
  * super-characters (64-bit keys) recursively, buckets in parallel (OpenMP).  The resulting order is
  * the plain suffix order with the end of the text smaller than every character, which is what
- * is_bwt() produces (is.c:197-243), so the files come out identical (tests/test_host_index.py).
+ * is_bwt() produces (is.c:197-243), so the files come out identical (tests/test_host_tools.py).  Long exact repeats (N runs
+ * of real assemblies, homopolymers, satellites), on which 16 characters per pass would be quadratic, are handed to a prefix
+ * doubling phase (finish_deep_groups); the scratch of a pass is sized for the group at hand, not for the largest bucket.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -158,8 +161,34 @@ static void kv_sort(kv_t *a, long n) { /* quicksort on key, median of three, exp
 	}
 }
 
-/* sorts the suffixes sa[0..m) that agree on their first `depth` characters */
-static void refine(const unsigned char *pk, uint64_t n, uint64_t *sa, long m, uint64_t depth, kv_t *tmp) {
+/* Groups the key refinement gives up on - a long exact repeat (an N run, a homopolymer, a satellite array, a duplicated
+ * segment), where advancing 16 characters per pass would cost (repeat length)^2 / 32 - are finished by prefix doubling. */
+#define DEPTH_MAX 512            /* characters after which a group still unsorted is handed over */
+#define STALL_MIN 4096           /* ... or earlier, when a group this large keeps (almost) all its members through a pass */
+typedef struct { uint64_t start, m, depth; } deep_t;
+static deep_t *g_deep; static size_t g_ndeep, g_capdeep;
+static void deep_add(uint64_t start, uint64_t m, uint64_t depth) {
+#pragma omp critical(bwb_deep)
+	{
+		if (g_ndeep == g_capdeep) {
+			g_capdeep = g_capdeep ? 2 * g_capdeep : 1024;
+			g_deep = (deep_t *)realloc(g_deep, g_capdeep * sizeof(deep_t));
+			if (!g_deep) bwb_die("is_bwt: out of memory");
+		}
+		g_deep[g_ndeep++] = (deep_t){ start, m, depth };
+	}
+}
+static kv_t *kv_alloc(long m) {
+	kv_t *t = (kv_t *)malloc(sizeof(kv_t) * (size_t)(m > 0 ? m : 1));
+	if (!t) bwb_die("is_bwt: Could not allocate memory for the BWT index construction, alloc'ing %llu Mb", (unsigned long long)((size_t)m * sizeof(kv_t) >> 20));
+	return t;
+}
+
+/* sorts the suffixes sa[0..m) that agree on their first `depth` characters; sa0 = start of the whole array (for deep_add) */
+static void refine(const unsigned char *pk, uint64_t n, uint64_t *sa0, uint64_t *sa, long m, uint64_t depth) {
+	kv_t small[48], *tmp = small, *heap = NULL; /* most groups are tiny: no allocation for them */
+	long tmp_cap = 48;
+	int stalled = 0;
 	while (m > 1) {
 		/* suffixes that end exactly here are the smallest of the group; among them the shorter (= larger
 		 * start) comes first */
@@ -168,32 +197,140 @@ static void refine(const unsigned char *pk, uint64_t n, uint64_t *sa, long m, ui
 			if (sa[i] + depth >= n) { uint64_t t = sa[i]; sa[i] = sa[ne]; sa[ne] = t; ne++; }
 		for (long i = 1; i < ne; i++) { uint64_t v = sa[i]; long j = i - 1; while (j >= 0 && sa[j] < v) { sa[j + 1] = sa[j]; j--; } sa[j + 1] = v; }
 		sa += ne; m -= ne;
-		if (m <= 1) return;
+		if (m <= 1) break;
+		/* (every member left has more than `depth` characters, so the doubling phase never looks past the end of the text) */
+		if (stalled || depth >= DEPTH_MAX) { deep_add((uint64_t)(sa - sa0), (uint64_t)m, depth); break; }
+		if (m > tmp_cap) { free(heap); tmp = heap = kv_alloc(m); tmp_cap = m; } /* sized for this group (groups only shrink), not for the largest bucket */
 		for (long i = 0; i < m; i++) { tmp[i].key = key16(pk, sa[i] + depth); tmp[i].idx = sa[i]; }
 		kv_sort(tmp, m);
 		for (long i = 0; i < m; i++) sa[i] = tmp[i].idx;
-		/* recurse into groups of equal keys; the last (or only) group is handled by the loop */
+		/* recurse into groups of equal keys; the largest is handled by the loop */
 		long g0 = 0, big0 = -1, bigm = 0;
 		for (long i = 1; i <= m; i++) {
 			if (i == m || tmp[i].key != tmp[g0].key) {
 				const long gm = i - g0;
-				if (gm > 1) {
-					if (big0 < 0) { big0 = g0; bigm = gm; }
-					else {
-						/* keep the larger group for the loop, recurse into the smaller with its own buffer */
-						long r0 = g0, rm = gm;
-						if (gm > bigm) { r0 = big0; rm = bigm; big0 = g0; bigm = gm; }
-						kv_t *t2 = (kv_t *)malloc(sizeof(kv_t) * (size_t)rm);
-						refine(pk, n, sa + r0, rm, depth + 16, t2);
-						free(t2);
-					}
-				}
+				if (gm > 1 && gm > bigm) { big0 = g0; bigm = gm; }
 				g0 = i;
 			}
 		}
-		if (big0 < 0) return;
+		g0 = 0;
+		for (long i = 1; i <= m; i++) {
+			if (i == m || tmp[i].key != tmp[g0].key) {
+				const long gm = i - g0;
+				if (gm > 1 && g0 != big0) refine(pk, n, sa0, sa + g0, gm, depth + 16);
+				g0 = i;
+			}
+		}
+		if (big0 < 0) break;
+		stalled = depth >= 48 && bigm >= STALL_MIN && bigm >= m - (m >> 3);
 		sa += big0; m = bigm; depth += 16;
 	}
+	free(heap);
+}
+
+/* sort of (key, idx) pairs with every core: chunks sorted in parallel, then merged pairwise */
+static void kv_sort_parallel(kv_t *a, long m, int nthreads) {
+	if (m < (1L << 18) || nthreads < 2) { kv_sort(a, m); return; }
+	int T = 1;
+	while (T * 2 <= nthreads && T < 64) T *= 2;
+	long *cut = (long *)malloc(sizeof(long) * (size_t)(T + 1));
+	for (int t = 0; t <= T; t++) cut[t] = m * t / T;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+	for (int t = 0; t < T; t++) kv_sort(a + cut[t], cut[t + 1] - cut[t]);
+	kv_t *b = kv_alloc(m), *src = a, *dst = b;
+	for (int w = 1; w < T; w *= 2) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+		for (int t = 0; t < T; t += 2 * w) {
+			long i = cut[t], ie = cut[t + w], j = ie, je = cut[t + 2 * w], o = cut[t];
+			while (i < ie && j < je) dst[o++] = (src[j].key < src[i].key) ? src[j++] : src[i++];
+			while (i < ie) dst[o++] = src[i++];
+			while (j < je) dst[o++] = src[j++];
+		}
+		kv_t *x = src; src = dst; dst = x;
+	}
+	if (src != a) memcpy(a, src, sizeof(kv_t) * (size_t)m);
+	free(b);
+	free(cut);
+}
+
+/* Prefix doubling (Larsson-Sadakane style) over the groups refine() handed over.  Every suffix outside them is at its final
+ * row; the members of a group occupy their final range of rows and agree on >= h characters, so their order is the order of
+ * the suffixes h characters further on, which ISA - the row of a placed suffix, the first row of its group otherwise - answers
+ * for both kinds.  Each round doubles h; only rows still in groups are touched.  SA = rows 0..n (SA[0] = n, the empty suffix). */
+static void finish_deep_groups(uint64_t *SA, uint64_t n) {
+	if (!g_ndeep) return;
+	uint64_t h = g_deep[0].depth, tot = 0;
+	for (size_t g = 0; g < g_ndeep; g++) { if (g_deep[g].depth < h) h = g_deep[g].depth; tot += g_deep[g].m; }
+	printf("Suffix sort: %zu group(s) with %llu suffixes share more than %llu characters; finishing them by prefix doubling\n", g_ndeep, (unsigned long long)tot, (unsigned long long)h);
+	uint64_t *ISA = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1));
+	if (!ISA) bwb_die("is_bwt: Could not allocate memory for the BWT index construction, alloc'ing %llu Mb", (unsigned long long)((n + 1) * 8 >> 20));
+#pragma omp parallel for schedule(static)
+	for (uint64_t r = 0; r <= n; r++) ISA[SA[r]] = r;
+	/* deep_t.start counts from SA[1] */
+	for (size_t g = 0; g < g_ndeep; g++) g_deep[g].start += 1;
+#pragma omp parallel for schedule(dynamic, 64)
+	for (size_t g = 0; g < g_ndeep; g++)
+		for (uint64_t k = 0; k < g_deep[g].m; k++) ISA[SA[g_deep[g].start + k]] = g_deep[g].start;
+	int nthreads = 1;
+#pragma omp parallel
+#pragma omp single
+	nthreads = omp_get_num_threads();
+	deep_t *cur = g_deep;
+	size_t ncur = g_ndeep;
+	g_deep = NULL; g_ndeep = g_capdeep = 0;
+	while (ncur) {
+		/* phase A: order every group by the rank of the suffix h further on (ISA is only read), remember the keys */
+		uint64_t **keys = (uint64_t **)calloc(ncur, sizeof(uint64_t *));
+		/* large groups one after the other with all threads, the rest in parallel */
+		for (size_t g = 0; g < ncur; g++) {
+			if (cur[g].m < (1u << 18)) continue;
+			const long m = (long)cur[g].m;
+			uint64_t *sa = SA + cur[g].start;
+			kv_t *t = kv_alloc(m);
+#pragma omp parallel for schedule(static)
+			for (long i = 0; i < m; i++) { t[i].key = ISA[sa[i] + h]; t[i].idx = sa[i]; }
+			kv_sort_parallel(t, m, nthreads);
+			keys[g] = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)m);
+			if (!keys[g]) bwb_die("is_bwt: out of memory");
+#pragma omp parallel for schedule(static)
+			for (long i = 0; i < m; i++) { sa[i] = t[i].idx; keys[g][i] = t[i].key; }
+			free(t);
+		}
+#pragma omp parallel for schedule(dynamic, 8)
+		for (size_t g = 0; g < ncur; g++) {
+			if (cur[g].m >= (1u << 18)) continue;
+			const long m = (long)cur[g].m;
+			uint64_t *sa = SA + cur[g].start;
+			kv_t *t = kv_alloc(m);
+			for (long i = 0; i < m; i++) { t[i].key = ISA[sa[i] + h]; t[i].idx = sa[i]; }
+			kv_sort(t, m);
+			keys[g] = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)m);
+			if (!keys[g]) bwb_die("is_bwt: out of memory");
+			for (long i = 0; i < m; i++) { sa[i] = t[i].idx; keys[g][i] = t[i].key; }
+			free(t);
+		}
+		/* phase B: split at key changes, give the members their new group row, collect what is still unsorted */
+#pragma omp parallel for schedule(dynamic, 8)
+		for (size_t g = 0; g < ncur; g++) {
+			const uint64_t m = cur[g].m, st = cur[g].start;
+			uint64_t g0 = 0;
+			for (uint64_t i = 1; i <= m; i++) {
+				if (i == m || keys[g][i] != keys[g][g0]) {
+					for (uint64_t k = g0; k < i; k++) ISA[SA[st + k]] = st + g0;
+					if (i - g0 > 1) deep_add(st + g0, i - g0, 2 * h);
+					g0 = i;
+				}
+			}
+			free(keys[g]);
+		}
+		free(keys);
+		free(cur);
+		cur = g_deep; ncur = g_ndeep;
+		g_deep = NULL; g_ndeep = g_capdeep = 0;
+		h *= 2;
+	}
+	free(cur);
+	free(ISA);
 }
 
 /* SA of seq[0..n) in the reference's row convention: SA[0] = n (empty suffix), is.c:197-206 */
@@ -206,30 +343,26 @@ static uint64_t *build_sa(const unsigned char *seq, uint64_t n) {
 	const int RB = 20; /* 5 characters */
 	const uint64_t NB = 1ull << RB;
 	uint64_t *cnt = (uint64_t *)calloc(NB + 1, sizeof(uint64_t));
+	uint64_t *fill = (uint64_t *)malloc(sizeof(uint64_t) * NB);
+	if (!cnt || !fill) bwb_die("is_bwt: out of memory");
 	/* bucket id = first 5 characters (zero padded); suffixes shorter than 5 sort first inside their bucket via refine() */
 #define BKT(i) (key16(pk, (i)) >> (64 - RB))
 	for (uint64_t i = 0; i < n; i++) cnt[BKT(i) + 1]++;
 	for (uint64_t b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
-	uint64_t *fill = (uint64_t *)malloc(sizeof(uint64_t) * NB);
 	memcpy(fill, cnt, sizeof(uint64_t) * NB);
 	uint64_t *S = SA + 1;
 	for (uint64_t i = 0; i < n; i++) S[fill[BKT(i)]++] = i;
 	free(fill);
-	uint64_t maxb = 0;
-	for (uint64_t b = 0; b < NB; b++) if (cnt[b + 1] - cnt[b] > maxb) maxb = cnt[b + 1] - cnt[b];
-#pragma omp parallel
-	{
-		kv_t *tmp = (kv_t *)malloc(sizeof(kv_t) * (size_t)(maxb ? maxb : 1));
-#pragma omp for schedule(dynamic, 16)
-		for (long b = 0; b < (long)NB; b++) {
-			const long m = (long)(cnt[b + 1] - cnt[b]);
-			if (m > 1) refine(pk, n, S + cnt[b], m, 0, tmp);
-		}
-		free(tmp);
+	g_ndeep = 0;
+#pragma omp parallel for schedule(dynamic, 16)
+	for (long b = 0; b < (long)NB; b++) {
+		const long m = (long)(cnt[b + 1] - cnt[b]);
+		if (m > 1) refine(pk, n, S, S + cnt[b], m, 0);
 	}
 #undef BKT
 	free(cnt);
 	free(pk);
+	finish_deep_groups(SA, n);
 	return SA;
 }
 

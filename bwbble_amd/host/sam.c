@@ -7,6 +7,7 @@
  * (bwb_hip_locate); MAPQ (the only floating point in the tool), CIGAR and text stay on the host.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include "bwb_host.h"
@@ -24,8 +25,21 @@ static int mapq(int top1, int top2, int num_mm, int max_mm) { /* align.c:738-746
 	return 23 < q ? 0 : 23 - q;
 }
 
+/* SA lookups of a contiguous share of the rows on one GPU (the index is replicated, like in align) */
+typedef struct { int device; const bwt_t *BWT; const uint64_t *rows; uint64_t *pos; size_t n; } locate_job_t;
+static void *locate_worker(void *arg) {
+	locate_job_t *j = (locate_job_t *)arg;
+	bwb_hip_ctx *ctx = NULL;
+	const bwtint_t hdr[5] = { j->BWT->length, j->BWT->num_words, j->BWT->num_sa, j->BWT->num_occ, j->BWT->sa0_index };
+	if (bwb_hip_ctx_create(j->device, hdr, j->BWT->C, j->BWT->bwt, j->BWT->O, &ctx) || bwb_hip_set_sa(ctx, j->BWT->SA, j->BWT->num_sa) ||
+	    bwb_hip_locate(ctx, j->rows, j->n, j->pos))
+		bwb_die("alns2sam: GPU %d: %s", j->device, bwb_hip_last_error());
+	bwb_hip_ctx_destroy(ctx);
+	return NULL;
+}
+
 void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFname, int is_multiref, int max_diff, int n_gpus) {
-	(void)is_multiref; (void)n_gpus;
+	(void)is_multiref;
 	printf("**** BWBBLE Alignment Evaluation/SAM File Generation ****\n");
 	size_t Ln = strlen(fastaFname) + 8;
 	char *bwtFname = (char *)malloc(Ln), *annFname = (char *)malloc(Ln);
@@ -49,13 +63,20 @@ void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFnam
 	for (size_t r = 0; r < n; r++)
 		if (alns->aln_off[r + 1] > alns->aln_off[r]) { rows[nm] = alns->alns[alns->aln_off[r]].L; which[nm] = r; nm++; }
 	if (nm) {
-		if (bwb_hip_device_count() < 1) bwb_die("alns2sam: no HIP device found (SA lookups run on the GPU)");
-		bwb_hip_ctx *ctx = NULL;
-		const bwtint_t hdr[5] = { BWT->length, BWT->num_words, BWT->num_sa, BWT->num_occ, BWT->sa0_index };
-		if (bwb_hip_ctx_create(0, hdr, BWT->C, BWT->bwt, BWT->O, &ctx) || bwb_hip_set_sa(ctx, BWT->SA, BWT->num_sa) ||
-		    bwb_hip_locate(ctx, rows, nm, pos))
-			bwb_die("alns2sam: %s", bwb_hip_last_error());
-		bwb_hip_ctx_destroy(ctx);
+		const int ndev = bwb_hip_device_count();
+		if (ndev < 1) bwb_die("alns2sam: no HIP device found (SA lookups run on the GPU)");
+		if (n_gpus < 1) n_gpus = 1;
+		if (n_gpus > ndev) bwb_die("alns2sam: -g %d asked for, %d HIP device(s) available", n_gpus, ndev);
+		if ((size_t)n_gpus > nm) n_gpus = (int)nm;
+		locate_job_t jobs[64];
+		pthread_t th[64];
+		if (n_gpus > 64) n_gpus = 64;
+		for (int g = 0; g < n_gpus; g++) { /* contiguous shares, like the read chunks of align (inexact_match.c:115-116) */
+			const size_t lo = (size_t)g * nm / (size_t)n_gpus, hi = (size_t)(g + 1) * nm / (size_t)n_gpus;
+			jobs[g] = (locate_job_t){ .device = g, .BWT = BWT, .rows = rows + lo, .pos = pos + lo, .n = hi - lo };
+			if (pthread_create(&th[g], NULL, locate_worker, &jobs[g])) bwb_die("alns2sam: cannot start a host thread");
+		}
+		for (int g = 0; g < n_gpus; g++) pthread_join(th[g], NULL);
 	}
 	uint64_t *ref_pos = (uint64_t *)calloc(n ? n : 1, 8);
 	for (size_t k = 0; k < nm; k++) ref_pos[which[k]] = pos[k];

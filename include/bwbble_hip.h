@@ -57,7 +57,7 @@ typedef struct {
 	const bwb_aln *alns;
 } bwb_result;
 
-/* Work/timing counters of the last batch_run (SURVEY.md 8(d) counting rules) */
+/* Work/timing counters since the last bwb_hip_reset_stats / bwb_hip_batch_run (SURVEY.md 8(d) counting rules) */
 typedef struct {
 	uint64_t visits_single;      /* rank-block visits made for the 7-code exact steps (calculate_d, exact tail) */
 	uint64_t visits_calc_d;      /* the part of visits_single made by the calculate_d kernel */
@@ -65,10 +65,13 @@ typedef struct {
 	uint64_t heap_pops, heap_pushes;
 	uint64_t n_alignments;
 	uint64_t n_overflow_reads;   /* reads re-run with a larger scratch class (still on the GPU) */
-	uint64_t n_heavy_reads;      /* reads that exceeded the phase-1 iteration budget and were restarted in the heavy pass */
-	double ms_calc_d;            /* HIP-event time of the calculate_d kernel(s) */
-	double ms_search;            /* HIP-event time of the inexact-search kernel(s), all passes */
-	double ms_total;             /* first launch .. last kernel done */
+	uint64_t n_parked_reads;     /* reads that were parked at the end of a slice and resumed by the next launch */
+	uint64_t bucket_loads_search; /* 128-byte device buckets the search kernel fetched (a same-bucket L-1/U pair counts once) */
+	uint64_t bucket_loads_calc_d; /* the same for the calculate_d kernel */
+	uint64_t lane_iterations, wave_iterations; /* search loop iterations of busy lanes / of waves: their ratio = lanes busy of 64 */
+	double ms_calc_d;            /* HIP-event time of the calculate_d kernel(s) that have finished */
+	double ms_search;            /* HIP-event time of the inexact-search kernel(s) that have finished, all passes */
+	double ms_total;             /* batch_run: wall time of the call */
 	uint32_t launches_calc_d, launches_search;
 } bwb_stats;
 
@@ -97,9 +100,26 @@ int bwb_hip_align_batch(bwb_hip_ctx *ctx, const bwb_params *p, const uint8_t *re
 /* The same in three steps, so that a caller can time the GPU work with inputs resident in HBM. */
 int bwb_hip_batch_upload(bwb_hip_ctx *ctx, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
                          uint32_t n_reads, uint32_t stride);
-int bwb_hip_batch_run(bwb_hip_ctx *ctx);                       /* kernels only; blocks until done */
+int bwb_hip_batch_run(bwb_hip_ctx *ctx);                       /* kernels only; blocks until done; resets the statistics first */
 int bwb_hip_batch_result(bwb_hip_ctx *ctx, bwb_result *out);  /* D2H copy of the hits */
 int bwb_hip_get_stats(bwb_hip_ctx *ctx, bwb_stats *out);
+int bwb_hip_reset_stats(bwb_hip_ctx *ctx);
+
+/* Streaming form of the same (what `bwbble align` uses for a FASTQ of many batches, inexact_match.c:103-165): up to
+ * BWB_MAX_SLOTS batches are resident per context.  slot_upload copies the reads to HBM on a copy stream (the caller's
+ * buffers are free when it returns); slot_submit queues calculate_d and one slice of the search for that slot and returns at
+ * once - a slice does not drain: the reads still under way when the slot's cursor runs out are parked and resumed by the
+ * next submitted slot's slice, so the heavy tail of one batch overlaps the bulk of the next; slot_wait blocks until every
+ * read of the slot is done (launching a draining slice if nothing else is queued); slot_result = slot_wait + D2H of the
+ * hits on a result stream, valid until the slot is uploaded again; flush = wait for every slot.  All slots in flight use
+ * the same parameters (a slot_upload with different ones flushes first).  Same result bytes as align_batch. */
+#define BWB_MAX_SLOTS 4
+int bwb_hip_slot_upload(bwb_hip_ctx *ctx, int slot, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
+                        uint32_t n_reads, uint32_t stride);
+int bwb_hip_slot_submit(bwb_hip_ctx *ctx, int slot);
+int bwb_hip_slot_wait(bwb_hip_ctx *ctx, int slot);
+int bwb_hip_slot_result(bwb_hip_ctx *ctx, int slot, bwb_result *out);
+int bwb_hip_flush(bwb_hip_ctx *ctx);
 
 /* calculate_d for the uploaded batch (inexact_match.c:171-254): D and D_seed of every read as
  * (num_diff, sa_intv_width) int32 pairs, out_D[n_reads][max_len+1][2], out_Dseed[n_reads][seed_length+1][2]
@@ -114,6 +134,9 @@ int bwb_hip_rank16(bwb_hip_ctx *ctx, const uint64_t *pos, size_t n, int inc, int
 /* Rank micro-benchmark: `n` pseudo-random Occ16 queries (seeded), repeated `iters` times with
  * everything resident; returns kernel milliseconds per iteration and a checksum of the results. */
 int bwb_hip_rank_bench(bwb_hip_ctx *ctx, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum);
+/* The same queries with the layout the alignment kernels use: one query per lane, every lane gathers its own 128-byte
+ * bucket and ranks all 15 codes (the octet version above splits one bucket over 8 lanes). Same checksum. */
+int bwb_hip_rank_bench_lane(bwb_hip_ctx *ctx, size_t n, int iters, uint64_t seed, double *ms_per_iter, uint64_t *checksum);
 
 /* SA[i] for n suffix-array rows via the invPsi walk (bwt.c:311-329); needs the sampled SA
  * (bwt.c:80) uploaded with bwb_hip_set_sa. Used by aln2sam (align.c:760-812). */

@@ -29,5 +29,5 @@ def test_default_params_mirror_reference_defaults(built):
 def test_code_object_targets_gfx950(built):
     data = open(bw.LIB_PATH, "rb").read()
     assert b"gfx950" in data
-    for k in (b"k_search", b"k_calc_d", b"k_rank16", b"k_relayout"):
+    for k in (b"kl_search", b"kl_calc_d", b"k_rank16", b"k_relayout", b"k_rank_bench_lane"):
         assert k in data

@@ -14,7 +14,9 @@ g = dist.Group(backend="gloo")
 lo, hi = dist.shard_bounds(1000003, g.world, g.rank)
 g.barrier()
 dt, kms, vis = g.reduce_step(1.0 + g.rank, 10.0 * (g.rank + 1), float(hi - lo))
-print(json.dumps({"rank": g.rank, "world": g.world, "lo": lo, "hi": hi, "dt": dt, "kms": kms, "vis": vis}))
+pairs = g.all_gather_pairs(100 + g.rank, 100 + (g.rank + 1) %% g.world)  # (own checksum, checksum of the right neighbour's sample)
+ring_ok = all(pairs[(r + 1) %% g.world][0] == pairs[r][1] for r in range(g.world))
+print(json.dumps({"rank": g.rank, "world": g.world, "lo": lo, "hi": hi, "dt": dt, "kms": kms, "vis": vis, "ring_ok": ring_ok}))
 g.close()
 """ % ROOT
 
@@ -35,7 +37,7 @@ def test_two_rank_gloo_protocol(tmp_path):
     # contiguous, disjoint, complete shards in rank order (the .aln of rank r precedes that of rank r+1)
     assert outs[0]["lo"] == 0 and outs[0]["hi"] == outs[1]["lo"] and outs[1]["hi"] == 1000003
     for o in outs:
-        assert o["dt"] == 2.0 and o["kms"] == 20.0 and o["vis"] == 1000003.0
+        assert o["dt"] == 2.0 and o["kms"] == 20.0 and o["vis"] == 1000003.0 and o["ring_ok"]
 
 
 def test_shard_bounds_cover_everything():

@@ -98,16 +98,105 @@ def test_scratch_overflow_classes_are_exact(mid, oracle, monkeypatch):
     ctx.close()
 
 
-def test_heavy_read_pass_is_exact(mid, oracle, monkeypatch):
-    """BWB_ITER_BUDGET parks long-running reads and restarts them in the one-read-per-octet pass."""
+@pytest.mark.parametrize("env", [{"BWB_FORCE_SLICES": "1"}, {"BWB_SLICE_ITERS": "150"}, {"BWB_SLICE_ITERS": "40", "BWB_FORCE_POS64": "1"},
+                                 {"BWB_SLICE_ITERS": "300", "BWB_POOL_GB": "0"}])
+def test_parked_and_resumed_reads_are_exact(mid, oracle, monkeypatch, env):
+    """Slices: a launch parks the reads under way (all per-lane state to the save area) and the next launch resumes them.
+    BWB_FORCE_SLICES parks when the cursor runs out; BWB_SLICE_ITERS parks every wave after that many loop iterations, so
+    every read is parked and resumed many times, in every mode (pop, exact tail, -P seeding), with a starved pool too."""
     d, fa = mid
-    monkeypatch.setenv("BWB_ITER_BUDGET", "1500")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     ctx = bw.Context(fa + ".bwt")
     idx = oracle.load_index(fa + ".bwt")
-    seqs, lens = synth_reads(fa, str(d / "h.fq"), 4000, 100, 9, sub=2.0)
+    seqs, lens = synth_reads(fa, str(d / "h.fq"), 4000, 100, 9, sub=2.0, indel=1.0, npct=1.0)
     st = check(ctx, oracle, idx, ["-n", "3"], seqs, lens)
-    assert st.n_heavy_reads > 0
+    assert st.n_parked_reads > 0 and st.launches_search > 1
+    check(ctx, oracle, idx, ["-n", "4", "-o", "2", "-e", "3"], seqs[:1500], lens[:1500])
+    check(ctx, oracle, idx, ["-P", "-n", "2"], seqs, lens)
+    check(ctx, oracle, idx, ["-S", "-n", "2"], seqs, lens)
     ctx.close()
+
+
+def test_streamed_slots_match_oracle(mid_ctx, oracle):
+    """The streaming interface: batches of different sizes go through the slots back to back (every slice parks its
+    unfinished reads for the next), slots are reused, and each batch's bytes equal the oracle's."""
+    d, fa, ctx, idx = mid_ctx
+    seqs, lens = synth_reads(fa, str(d / "s.fq"), 9000, 100, 21, sub=2.0, indel=1.0, npct=1.0)
+    flags = ["-n", "3"]
+    p = bw.params(flags)
+    cuts = [0, 2500, 2600, 5600, 5600, 7000, 9000]   # includes an empty batch and a 100-read one
+    want = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        data, _, _ = oracle.align_encoded(idx, seqs[lo:hi], lens[lo:hi], oracle.params(flags))
+        want.append(data)
+    ctx.flush()
+    ctx.reset_stats()
+    got = [None] * len(want)
+    nslot = bw.MAX_SLOTS
+    for j, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        slot = j % nslot
+        if j >= nslot:   # the slot is reused: take its result first
+            off, alns = ctx.slot_result(slot)
+            got[j - nslot] = bw.aln_bytes(off, alns)
+        ctx.slot_upload(slot, p, seqs[lo:hi], lens[lo:hi])
+        ctx.slot_submit(slot)
+    for j in range(max(0, len(want) - nslot), len(want)):
+        off, alns = ctx.slot_result(j % nslot)
+        got[j] = bw.aln_bytes(off, alns)
+    ctx.flush()
+    assert got == want
+    st = ctx.stats()
+    _, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags))
+    assert st.visits_single + st.visits_alphabet == ost.visits_single + ost.visits_alphabet
+    assert st.heap_pops == ost.heap_pops and st.heap_pushes == ost.heap_pushes
+    assert st.n_parked_reads > 0
+    # a different parameter set while slots are alive flushes first; then the one-batch interface still works
+    ctx.slot_upload(0, p, seqs[:500], lens[:500])
+    ctx.slot_submit(0)
+    check(ctx, oracle, idx, ["-n", "2"], seqs[:800], lens[:800])
+
+
+def test_unrepresentable_reads_get_empty_records(mid_ctx, oracle):
+    """A read longer than 255 bases (aln_entry_t.i is 8-bit, align.h:104) no longer fails the batch: empty record, the others exact."""
+    d, fa, ctx, idx = mid_ctx
+    seqs, lens = synth_reads(fa, str(d / "u.fq"), 300, 100, 33)
+    big = np.full((len(lens), 300), 4, dtype=np.uint8)
+    big[:, :100] = seqs
+    lens2 = lens.copy()
+    lens2[7] = 300
+    big[7, :] = 0
+    off, alns = ctx.align(bw.params(["-n", "2"]), big, lens2)
+    lens3 = lens.copy()
+    lens3[7] = 0
+    want, _, _ = oracle.align_encoded(idx, seqs, lens3, oracle.params(["-n", "2"]))
+    assert bw.aln_bytes(off, alns) == want
+    # -P with a read shorter than 12 bases: the same
+    lens4 = lens.copy()
+    lens4[3] = 11
+    off, alns = ctx.align(bw.params(["-P", "-n", "1"]), seqs, lens4)
+    lens5 = lens4.copy()
+    lens5[3] = 0
+    want, _, _ = oracle.align_encoded(idx, seqs, lens5, oracle.params(["-P", "-n", "1"]))
+    assert bw.aln_bytes(off, alns) == want
+
+
+def test_rank_bench_layouts_agree(mid_ctx):
+    """The two rank micro-benchmarks (octet-cooperative, one query per lane) answer the same queries: same checksum."""
+    d, fa, ctx, idx = mid_ctx
+    _, a = ctx.rank_bench(1 << 16, iters=1, seed=5)
+    _, b = ctx.rank_bench(1 << 16, iters=1, seed=5, lane=True)
+    assert a == b and a != 0
+
+
+def test_bucket_load_counter(mid_ctx, oracle):
+    """device buckets fetched <= algorithmic visits (a same-bucket L-1/U pair is fetched once), and not zero"""
+    d, fa, ctx, idx = mid_ctx
+    seqs, lens = synth_reads(fa, str(d / "b.fq"), 2000, 100, 44)
+    st = check(ctx, oracle, idx, ["-n", "2"], seqs, lens)
+    vis_search = st.visits_single + st.visits_alphabet - st.visits_calc_d
+    assert 0 < st.bucket_loads_calc_d <= st.visits_calc_d
+    assert 0 < st.bucket_loads_search <= vis_search + 2 * st.heap_pops  # (visits of pruned / unfinished work are not counted as algorithmic)
 
 
 def test_force_64bit_positions(mid, oracle, monkeypatch):

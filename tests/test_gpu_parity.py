@@ -96,5 +96,7 @@ def test_unsupported_parameters_fail_loudly(toy_ctx):
     lens = np.array([40], dtype=np.uint16)
     with pytest.raises(bw.BwbError):
         toy_ctx.align(bw.params(["-o", "9"]), seqs, lens)
-    with pytest.raises(bw.BwbError):  # -P with a read shorter than 12 bases (the reference reads before its buffer there)
-        toy_ctx.align(bw.params(["-P"]), seqs, np.array([11], dtype=np.uint16))
+    with pytest.raises(bw.BwbError):
+        toy_ctx.align(bw.params(["-n", "200"]), seqs, lens)
+    with pytest.raises(bw.BwbError):  # result of a slot that was never submitted
+        toy_ctx.slot_result(3)

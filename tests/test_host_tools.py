@@ -73,6 +73,26 @@ def test_cli_align_multi_chunk_order(toy_dir, golden):
 
 
 @pytest.mark.gpu
+def test_cli_align_two_workers_on_one_device(toy_dir, golden):
+    """`align -g 2` with both workers mapped to device 0: two host threads, two contexts, shared chunk cursor, ordered writer
+    (the product's multi-GPU path, host/align_gpu.c) - the bytes must not depend on which worker took which chunk."""
+    out = toy_dir / "g2.aln"
+    env = dict(os.environ, BWB_DEVICE_MAP="0,0", BWB_CHUNK="97", BWB_POOL_GB="1")
+    log = subprocess.run([bw.HOST_BIN, "align", "-n", "3", "-g", "2", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(out)],
+                         check=True, env=env, stdout=subprocess.PIPE, text=True).stdout
+    assert "GPUs: 2" in log
+    assert open(out, "rb").read() == open(os.path.join(golden, "toy_n3.aln"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_more_gpus_than_present_fails_loudly(toy_dir, golden):
+    n = bw.device_count()
+    r = subprocess.run([bw.HOST_BIN, "align", "-g", str(n + 1), str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(toy_dir / "y.aln")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "asked for" in r.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fq,aln,sam", [("toy.fq", "toy_n3.aln", "toy_n3.sam"), ("ragged.fq", "ragged_n4gap.aln", "ragged_n4gap.sam")])
 def test_cli_aln2sam_writes_reference_sam(toy_dir, golden, fq, aln, sam):
     out = toy_dir / (sam + ".out")
@@ -100,3 +120,62 @@ def test_cli_align_without_gpu_fails_loudly(toy_dir, golden):
     r = subprocess.run([bw.HOST_BIN, "align", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(toy_dir / "x.aln")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0 and "no HIP device" in r.stdout
+
+
+def _repeat_rich_fasta(path):
+    """Deterministic FASTA with what real assemblies have and iid text has not: a long N run, a homopolymer, a tandem array, an
+    exact segmental duplication (also across records), on top of random sequence."""
+    rng = np.random.default_rng(20240917)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rnd = lambda n: acgt[rng.integers(0, 4, n)].tobytes()
+    dup = rnd(40000)
+    rec1 = rnd(50000) + b"N" * 300000 + rnd(30000) + b"A" * 120000 + rnd(20000) + dup + rnd(10000) + b"ACGGT" * 16000 + rnd(5000)
+    rec2 = rnd(7000) + dup + b"N" * 70000 + rnd(9000) + b"T" * 30000 + rnd(3000)
+    with open(path, "wb") as f:
+        for name, rec in ((b"chrA", rec1), (b"chrB with spaces", rec2)):
+            f.write(b">" + name + b"\n")
+            for i in range(0, len(rec), 60):
+                f.write(rec[i:i + 60] + b"\n")
+
+
+# sha256 of the .bwt the REAL reference (oracle/_ref/bwbble index, sais-lite) writes for _repeat_rich_fasta
+REPEAT_RICH_BWT_SHA256 = "92fab3456babf506484605f2789d141d69ea37febc683174da300278151b8dea"
+
+
+def test_index_long_repeats_match_reference(built, tmp_path):
+    """N runs / homopolymers / tandem arrays / exact duplications: the key-refinement suffix sort hands them to its prefix
+    doubling phase; the .bwt must still be the reference's, byte for byte (index.c not scale-safe on real genomes)."""
+    import hashlib
+    fa = tmp_path / "rep.fa"
+    _repeat_rich_fasta(fa)
+    log = run([bw.HOST_BIN, "index", str(fa)])
+    assert "prefix doubling" in log
+    data = open(str(fa) + ".bwt", "rb").read()
+    # (1) the BWT inverts to the text: walk LF from the row of the empty suffix (row 0), is.c:197-243 row convention
+    b = bw.BwtFile(str(fa) + ".bwt")
+    text = np.fromfile(str(fa) + ".ref", dtype=np.uint8)
+    n = len(text)
+    assert b.length == n + 1
+    w = np.asarray(b.bwt, dtype=np.uint32)
+    L = ((w[:, None] >> (28 - 4 * np.arange(8, dtype=np.uint32))[None, :]) & 15).astype(np.int16).reshape(-1)[:n + 1] + 1
+    L[b.sa0_index] = 0  # the row whose suffix is the whole text: its "previous character" is the end-of-text sentinel
+    order = np.argsort(L, kind="stable")
+    LF = np.empty(n + 1, dtype=np.int64)
+    LF[order] = np.arange(n + 1)
+    out = np.empty(n, dtype=np.uint8)
+    i = 0
+    Ll, LFl = (L - 1).tolist(), LF.tolist()
+    for k in range(n - 1, -1, -1):
+        out[k] = Ll[i]
+        i = LFl[i]
+    assert i == b.sa0_index and np.array_equal(out, text)
+    # (2) byte-identical to the reference's file (hash recorded from the reference run in the build container) ...
+    assert hashlib.sha256(data).hexdigest() == REPEAT_RICH_BWT_SHA256
+    # ... and, where the reference binary is present, re-checked against a fresh run of it
+    ref_bin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "bwbble")
+    if os.path.exists(ref_bin) and os.path.isdir("/root/reference"):
+        fb = tmp_path / "ref.fa"
+        shutil.copy(fa, fb)
+        run([ref_bin, "index", str(fb)])
+        assert open(str(fb) + ".bwt", "rb").read() == data
+        assert open(str(fb) + ".ann", "rb").read() == open(str(fa) + ".ann", "rb").read()
