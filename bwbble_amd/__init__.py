@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbwbble_hip.so")
+LIB_PATH = os.environ.get("BWB_LIB") or os.path.join(HERE, "libbwbble_hip.so")  # BWB_LIB: tests load the `make testlib` build
+TEST_LIB_PATH = os.path.join(HERE, "libbwbble_hip_test.so")
 HOST_BIN = os.path.join(HERE, "bin", "bwbble")
 SYNTH_BIN = os.path.join(HERE, "bin", "bwb_synth")
 
@@ -58,9 +59,9 @@ class BwbError(RuntimeError):
     pass
 
 
-def build():
-    """Compiles the HIP library and the host tools in-tree (hipcc --offload-arch=gfx950)."""
-    subprocess.run(["make", "-s", "-C", HERE], check=True)
+def build(testlib=False):
+    """Compiles the HIP library and the host tools in-tree (hipcc --offload-arch=gfx950); testlib: the test build as well."""
+    subprocess.run(["make", "-s", "-C", HERE] + (["all", "testlib"] if testlib else []), check=True)
 
 
 def lib():
@@ -82,7 +83,7 @@ def lib():
         L.bwb_hip_rank_bench.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.bwb_hip_rank_bench_lane.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.bwb_hip_reset_stats.argtypes = [C.c_void_p]
-        L.bwb_hip_slot_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.bwb_hip_slot_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.bwb_hip_slot_submit.argtypes = [C.c_void_p, C.c_int]
         L.bwb_hip_slot_wait.argtypes = [C.c_void_p, C.c_int]
         L.bwb_hip_slot_result.argtypes = [C.c_void_p, C.c_int, C.POINTER(Result)]
@@ -175,12 +176,15 @@ class Context:
         _chk(lib().bwb_hip_batch_run(self._h))
 
     # -- streaming API: up to MAX_SLOTS batches resident, slices that park instead of draining ---------------------
-    def slot_upload(self, slot, p, seqs, lens):
+    def slot_upload(self, slot, p, seqs, lens, carry=None):
+        """carry: codes of the last read longer than the seed that precedes this batch in the file (D_seed of leading short reads)"""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         lens = np.ascontiguousarray(lens, dtype=np.uint16)
         if seqs.ndim != 2 or len(lens) != seqs.shape[0]:
             raise ValueError("seqs must be (n_reads, stride) uint8 with one length per row")
-        _chk(lib().bwb_hip_slot_upload(self._h, slot, C.byref(p), seqs.ctypes.data, lens.ctypes.data, seqs.shape[0], max(seqs.shape[1], 1)))
+        carry = None if carry is None else np.ascontiguousarray(carry, dtype=np.uint8)
+        _chk(lib().bwb_hip_slot_upload(self._h, slot, C.byref(p), seqs.ctypes.data, lens.ctypes.data, seqs.shape[0], max(seqs.shape[1], 1),
+                                       None if carry is None else carry.ctypes.data, 0 if carry is None else len(carry)))
 
     def slot_submit(self, slot):
         _chk(lib().bwb_hip_slot_submit(self._h, slot))

@@ -22,7 +22,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define BWB_SB_SHIFT 24                 /* blocks per superblock = 2^24 */
+#ifndef BWB_SB_SHIFT
+#define BWB_SB_SHIFT 24                 /* blocks per superblock = 2^24 (the test build `make testlib` uses 13, so that a 6 M-row index
+                                           spans several superblocks like a 6.85 G-row one does) */
+#endif
 #define BWB_NSB_MAX 8                   /* up to 2^34 BWT characters */
 #define BWB_ROW_NEG (BWB_NSB_MAX)       /* base row for position -1      : C[j]   (bwt.c:393-410) */
 #define BWB_ROW_END (BWB_NSB_MAX + 1)   /* base row for position length-1: C[j+1] (bwt.c:375-392) */

@@ -90,7 +90,10 @@ struct ScratchClass {
 struct Slot {
 	bool uploaded = false, submitted = false, complete = false, fetched = false;
 	uint32_t n_reads = 0, stride = 0, maxlen = 0, dstride = 0;
-	DevMem d_reads, d_lens, d_dbuf, d_status, d_n, d_off, d_worklist, d_log, d_ctl, d_dbg_iters;
+	DevMem d_reads, d_lens, d_dbuf, d_status, d_n, d_off, d_worklist, d_log, d_ctl, d_dbg_iters, d_src;
+	uint32_t n_tot = 0;           /* n_reads, plus one when the carried read (the source of a leading short read's D_seed) rides along for kl_calc_d */
+	bool inherit = false;         /* some read takes its D_seed from an earlier one (d_src) */
+	std::vector<uint32_t> h_src;
 	uint64_t log_cap = 0;
 	PinMem h_reads, h_lens, h_cnt, h_off, h_log, h_ctl;
 	std::vector<uint8_t> h_status;
@@ -264,9 +267,15 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	size_t fr = 0, tot = 0;
 	HIPCHK(hipMemGetInfo(&fr, &tot));
 	fr += c->d_pool.bytes; /* what would be free without the current pool */
-	/* Ceiling: half of what is free (the rest is for the scratch classes, their pool and the slots), and what the regions can
-	 * name: a state word holds a 26-bit chunk index relative to the block's region. */
-	const size_t ceiling = std::min<size_t>(fr / 2, (size_t)POOL_REGIONS << 36);
+	/* Ceiling: what is free (the index, the class-0 scratch and the first slot are allocated by now) minus what is still to
+	 * come - the scratch of the re-run classes and their pool, three more slots like the largest so far, some slack - and what
+	 * the regions can name: a state word holds a 26-bit chunk index relative to the block's region. */
+	const size_t isz = c->pos32 ? 8 : 16;
+	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * 32), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * 32);
+	size_t slot_bytes = 0;
+	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * 32);
+	const size_t reserve = cls1 + cls2 + ((size_t)8 << 30) + 3 * slot_bytes + ((size_t)4 << 30);
+	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
 	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
 	const size_t lanes = std::min<size_t>(max_reads_resident(c), (size_t)c->num_cu * 2 * LANE_BLOCK);
@@ -291,7 +300,7 @@ static int ensure_pool2(bwb_hip_ctx *c) {
 	if (c->d_pool2.p) return BWB_OK;
 	size_t fr = 0, tot = 0;
 	HIPCHK(hipMemGetInfo(&fr, &tot));
-	size_t want = std::min<size_t>((size_t)16 << 30, fr / 4);
+	size_t want = std::min<size_t>((size_t)8 << 30, fr / 4);
 	if (getenv("BWB_POOL_GB")) want = std::max<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, (size_t)256 << 20);
 	want = std::max<size_t>(want, (size_t)64 << 20) & ~(size_t)(POOL_REGIONS * 4096 - 1);
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the chunk pool of the re-run classes");
@@ -315,10 +324,8 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	} else if (k == 1) {
 		blocks = (uint32_t)std::max(1, c->num_cu / 2); lcap = 8192; acap = 1024;
 	} else {
-		blocks = 4; lcap = 1u << 20; acap = 1u << 16;
+		blocks = 1; lcap = 1u << 20; acap = 1u << 16;
 	}
-	int rc = k == 0 ? ensure_pool(c) : ensure_pool2(c);
-	if (rc) return rc;
 	const uint32_t nslots = blocks * LANE_BLOCK;
 	const size_t isz = c->pos32 ? 8 : 16;
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -349,7 +356,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.keep = c->keep;
 	s.blocks = blocks;
 	s.ready = true;
-	return BWB_OK;
+	return k == 0 ? ensure_pool(c) : ensure_pool2(c); /* (after the scratch: the class-0 pool takes what is left over) */
 }
 
 static hipEvent_t get_event(bwb_hip_ctx *c) {
@@ -406,7 +413,7 @@ extern "C" int bwb_hip_flush(bwb_hip_ctx *c) {
 }
 
 extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
-                                   uint32_t n_reads, uint32_t stride) {
+                                   uint32_t n_reads, uint32_t stride, const uint8_t *carry_seq, uint32_t carry_len) {
 	if (!c || !p || si < 0 || si >= BWB_MAX_SLOTS || (n_reads && (!reads_fwd || !lens)) || stride == 0) return fail(BWB_E_ARG, "slot_upload: bad argument");
 	int nb = 0;
 	int rc = check_params(p, &nb);
@@ -426,15 +433,38 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	/* Reads the kernels cannot represent (longer than 255 bases: aln_entry_t.i is 8-bit, align.h:104; shorter than 12 with -P:
 	 * read2index, align.c:174-186, reads before the buffer) get an empty record and a warning instead of failing the batch. */
 	uint32_t maxlen = 0, n_bad = 0;
+	/* D_seed of the reads that are not longer than the seed: that of the last longer read before them (k_dseed_inherit).
+	 * `carry` = that read for the head of the batch, when the caller knows one from earlier in the file. */
+	const uint32_t sl = (uint32_t)p->seed_length;
+	auto is_source = [&](const uint8_t *seq, uint32_t len) { /* computes D_seed (inexact_match.c:62-64) and is not skipped by -P (:50-57) */
+		if (!(sl && len > sl) || len > 255) return false;
+		if (p->use_precalc) { if (len < PRECALC_LEN) return false; for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) return false; }
+		return true;
+	};
+	const bool ghost = carry_seq && is_source(carry_seq, carry_len) && n_reads;
+	uint32_t last = ghost ? n_reads : NONE32;
+	s.inherit = false;
+	s.h_src.clear();
 	for (uint32_t i = 0; i < n_reads; i++) {
 		const bool bad = lens[i] > 255 || lens[i] > stride || (p->use_precalc && lens[i] < PRECALC_LEN);
-		if (bad) n_bad++; else maxlen = std::max<uint32_t>(maxlen, lens[i]);
+		if (bad) { n_bad++; continue; }
+		maxlen = std::max<uint32_t>(maxlen, lens[i]);
+		if (is_source(reads_fwd + (size_t)i * stride, lens[i])) last = i;
+		else if (sl && lens[i] && lens[i] <= sl && last != NONE32) {
+			if (!s.inherit) { s.h_src.assign(n_reads, NONE32); s.inherit = true; }
+			s.h_src[i] = last;
+		}
 	}
+	const bool use_ghost = ghost && s.inherit; /* (the carried read only matters when a short read precedes the batch's first longer one) */
+	if (s.inherit && !use_ghost) for (uint32_t i = 0; i < n_reads; i++) if (s.h_src[i] == n_reads) s.h_src[i] = NONE32;
+	if (s.inherit) { bool any = false; for (uint32_t v : s.h_src) any |= v != NONE32; s.inherit = any; }
+	if (use_ghost) maxlen = std::max<uint32_t>(maxlen, carry_len);
+	s.n_tot = n_reads + (use_ghost && s.inherit ? 1u : 0u);
 	if (n_bad) fprintf(stderr, "[bwbble_hip] warning: %u read(s) longer than 255 bases%s get an empty alignment record\n", n_bad, p->use_precalc ? " or shorter than 12 (-P)" : "");
 	s.n_reads = n_reads; s.stride = std::min<uint32_t>(stride, std::max<uint32_t>(maxlen, 1)); s.maxlen = maxlen;
 	/* per read: an 8-byte record {D pair, D_seed pair, base} for i = 0..maxlen+1, then 16 bytes (work, N count) */
 	s.dstride = 8 * (maxlen + 2) + 16;
-	const size_t nr = n_reads ? n_reads : 1;
+	const size_t nr = s.n_tot ? s.n_tot : 1;
 	HIPCHK(s.d_reads.reserve(nr * s.stride));
 	HIPCHK(s.d_lens.reserve(nr * 2));
 	HIPCHK(s.d_dbuf.reserve(nr * s.dstride));
@@ -460,9 +490,15 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 			hl[i] = bad ? 0 : lens[i];
 			memcpy(hr + (size_t)i * s.stride, reads_fwd + (size_t)i * stride, bad ? 0 : lens[i]);
 		}
-	if (n_reads) {
-		HIPCHK(hipMemcpyAsync(s.d_reads.p, hr, (size_t)n_reads * s.stride, hipMemcpyHostToDevice, c->cstream));
-		HIPCHK(hipMemcpyAsync(s.d_lens.p, hl, (size_t)n_reads * 2, hipMemcpyHostToDevice, c->cstream));
+	if (s.n_tot > n_reads) { hl[n_reads] = (uint16_t)carry_len; memcpy(hr + (size_t)n_reads * s.stride, carry_seq, carry_len); }
+	if (s.n_tot) {
+		HIPCHK(hipMemcpyAsync(s.d_reads.p, hr, (size_t)s.n_tot * s.stride, hipMemcpyHostToDevice, c->cstream));
+		HIPCHK(hipMemcpyAsync(s.d_lens.p, hl, (size_t)s.n_tot * 2, hipMemcpyHostToDevice, c->cstream));
+	}
+	if (s.inherit) {
+		HIPCHK(s.d_src.reserve((size_t)n_reads * 4));
+		HIPCHK(hipMemcpyAsync(s.d_src.p, s.h_src.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, c->cstream));
+		HIPCHK(hipStreamSynchronize(c->cstream)); /* (h_src is pageable) */
 	}
 	/* the slot's entry of the device table */
 	SlotDesc &d = c->h_descs[si];
@@ -503,6 +539,15 @@ static int launch_calc_d(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
 		fprintf(stderr, "[bwb] kl_calc_d class %d slot %d: %u reads, grid %u, %.3f ms\n", k, si, n_work, grid, ms);
 	}
+	return BWB_OK;
+}
+
+/* reads not longer than the seed take the D_seed bounds of the last longer read before them (k_dseed_inherit) */
+static int launch_inherit(bwb_hip_ctx *c, int si) {
+	Slot &s = c->slots[si];
+	if (!s.inherit) return BWB_OK;
+	hipLaunchKernelGGL(k_dseed_inherit, dim3((s.n_reads + 255) / 256), dim3(256), 0, c->stream, c->h_descs[si].b, s.d_src.as<uint32_t>(), s.n_reads);
+	HIPCHK(hipGetLastError());
 	return BWB_OK;
 }
 
@@ -577,8 +622,10 @@ static int submit(bwb_hip_ctx *c, int si, bool suspend) {
 	s.submitted = true; s.complete = false; s.fetched = false;
 	if (s.n_reads == 0) { s.complete = true; s.launch = c->n_launches; return BWB_OK; }
 	HIPCHK(hipMemsetAsync(s.d_n.p, 0, (size_t)s.n_reads * 4, c->stream));
-	HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_reads, c->stream));
-	rc = launch_calc_d(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), nullptr, nullptr);
+	HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_tot, c->stream));
+	rc = launch_calc_d(c, 0, si, nullptr, s.n_tot, s.ctl_counter(), nullptr, nullptr);
+	if (rc) return rc;
+	rc = launch_inherit(c, si);
 	if (rc) return rc;
 	rc = launch_search(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), suspend);
 	if (rc) return rc;
@@ -634,7 +681,8 @@ static int grow_log(bwb_hip_ctx *c, int si) {
 static int rerun_overflows(bwb_hip_ctx *c, int si) {
 	Slot &s = c->slots[si];
 	std::vector<uint32_t> todo, dids, list;
-	auto load_status = [&]() { s.h_status.resize(s.n_reads); return fetch(c, s.h_status.data(), s.d_status.p, s.n_reads); };
+	/* (n_tot: a carried read that rides along for its D_seed can overflow calculate_d too; it is never searched) */
+	auto load_status = [&]() { s.h_status.resize(s.n_tot); return fetch(c, s.h_status.data(), s.d_status.p, s.n_tot); };
 	auto put_worklist = [&](const std::vector<uint32_t> &v) -> int {
 		HIPCHK(hipMemcpyAsync(s.d_worklist.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
@@ -644,8 +692,8 @@ static int rerun_overflows(bwb_hip_ctx *c, int si) {
 		int rc = load_status();
 		if (rc) return rc;
 		todo.clear(); dids.clear();
-		for (uint32_t i = 0; i < s.n_reads; i++) {
-			if (s.h_status[i] != ST_OK) todo.push_back(i);
+		for (uint32_t i = 0; i < s.n_tot; i++) {
+			if (s.h_status[i] != ST_OK && i < s.n_reads) todo.push_back(i);
 			if (s.h_status[i] == ST_D_OVF) dids.push_back(i);
 		}
 		if (todo.empty()) return BWB_OK;
@@ -656,6 +704,8 @@ static int rerun_overflows(bwb_hip_ctx *c, int si) {
 			rc = put_worklist(dids);
 			if (rc) return rc;
 			rc = launch_calc_d(c, k, si, s.d_worklist.as<uint32_t>(), (uint32_t)dids.size(), s.ctl_counter2(), nullptr, nullptr);
+			if (rc) return rc;
+			rc = launch_inherit(c, si); /* sources that were late are there now (a read whose source still is not stays ST_D_OVF) */
 			if (rc) return rc;
 			HIPCHK(hipStreamSynchronize(c->stream));
 			rc = load_status();
@@ -683,7 +733,7 @@ static int rerun_overflows(bwb_hip_ctx *c, int si) {
 	}
 	int rc = load_status();
 	if (rc) return rc;
-	for (uint32_t i = 0; i < s.n_reads; i++)
+	for (uint32_t i = 0; i < s.n_tot; i++)
 		if (s.h_status[i] != ST_OK) return fail(BWB_E_OVERFLOW, "a read exceeded the largest per-read scratch class");
 	return BWB_OK;
 }
@@ -711,13 +761,14 @@ static int slot_wait(bwb_hip_ctx *c, int si) {
 	int rc = resolve_times(c, false);
 	if (rc) return rc;
 	/* anything that needs a larger scratch class?  (one byte per read; almost always all zero) */
-	s.h_status.resize(s.n_reads);
-	rc = fetch(c, s.h_status.data(), s.d_status.p, s.n_reads);
+	s.h_status.resize(s.n_tot);
+	rc = fetch(c, s.h_status.data(), s.d_status.p, s.n_tot);
 	if (rc) return rc;
 	bool clean = true;
-	for (uint32_t i = 0; i < s.n_reads && clean; i++) clean = s.h_status[i] == ST_OK;
+	for (uint32_t i = 0; i < s.n_tot && clean; i++) clean = s.h_status[i] == ST_OK;
 	if (!clean) { rc = rerun_overflows(c, si); if (rc) return rc; }
 	s.complete = true;
+	if (!any_in_flight(c)) c->parked = false; /* every read of every submitted slot is done: nothing can be parked any more */
 	return BWB_OK;
 }
 
@@ -779,7 +830,7 @@ extern "C" int bwb_hip_batch_upload(bwb_hip_ctx *c, const bwb_params *p, const u
 	if (!c) return fail(BWB_E_ARG, "batch_upload: null context");
 	int rc = bwb_hip_flush(c); /* this interface owns the context: nothing else may be in flight */
 	if (rc) return rc;
-	rc = bwb_hip_slot_upload(c, 0, p, reads_fwd, lens, n_reads, stride);
+	rc = bwb_hip_slot_upload(c, 0, p, reads_fwd, lens, n_reads, stride, nullptr, 0);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(c->cstream));
 	HIPCHK(hipStreamSynchronize(c->stream));

@@ -184,6 +184,23 @@ __global__ void k_gather(const uint4 *log, const uint64_t *off, const uint32_t *
 	for (uint32_t t = ol; t < cnt; t += 8) dst[d + t] = log[so + t];
 }
 
+/* D_seed of a read that is not longer than the seed.  The reference computes D_seed only when len > seed_length
+ * (inexact_match.c:62-64) but inexact_match reads it regardless (:321-328,408-415): the serial path (-t 1, one buffer for the
+ * whole file, :35) therefore sees the bounds of the LAST LONGER READ BEFORE IT in the file - zeros when there is none.
+ * src[r] names that read (host: slot_upload); the per-position records carry {Dseed[si-1], Dseed[si-2]} with
+ * si = i - (len - seed_length), so read r takes the pair of position i + len_q - len_r of read q.  Runs after kl_calc_d. */
+__global__ void k_dseed_inherit(Batch b, const uint32_t *src, uint32_t n) {
+	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n) return;
+	const uint32_t q = src[r];
+	if (q == NONE32) return;
+	if (b.status[q] == ST_D_OVF) { b.status[r] = ST_D_OVF; return; } /* its source waits for a larger scratch class: so does this read */
+	const int lr = b.lens[r], lq = b.lens[q];
+	uint8_t *rr = b.dbuf + (size_t)r * b.dstride;
+	const uint8_t *rq = b.dbuf + (size_t)q * b.dstride;
+	for (int i = 1; i <= lr; i++) *(uint16_t *)(rr + 8 * i + 2) = *(const uint16_t *)(rq + 8 * (i + lq - lr) + 2);
+}
+
 /* SA[row] by the invPsi walk (bwt.c:311-329): one octet per row */
 __global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_t *SA, uint64_t sa0_index, const uint64_t *rows, uint64_t n, uint64_t *out) {
 	__shared__ uint64_t s_base[BWB_BASE_ROWS * 16];

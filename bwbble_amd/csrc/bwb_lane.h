@@ -368,6 +368,15 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 /* ============================================================================================
  * k_search (one read per lane)
  * ========================================================================================== */
+/* Test build only (`make testlib`): heap entries store 64-bit positions plus this constant, so that the three high bits of L
+ * and U that a 16-byte entry packs into its last word (positions >= 2^32: only a > 4.3 G-row index has them) are exercised
+ * by a small index.  0 in the product. */
+#ifndef BWB_TEST_POS_BIAS
+#define BWB_TEST_POS_BIAS 0ull
+#endif
+template <typename P> __device__ __forceinline__ P pos_enc(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v + (uint64_t)BWB_TEST_POS_BIAS) : v; }
+template <typename P> __device__ __forceinline__ P pos_dec(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v - (uint64_t)BWB_TEST_POS_BIAS) : v; }
+
 /* heap entry.  NARROW (max_gapo <= 1): 16 bytes {L lo, U lo, i|mm|go|ge, state|alen<<2|run<<10|L hi<<26|U hi<<29};
  * WIDE: 32 bytes {L, U (64-bit each)} {i|mm|go|ge, state|alen<<8, runs lo, runs hi}.
  * runs: one 16-bit word per gap open: start | len<<8 | isD<<15, 0xFFFF = unused. */
@@ -479,10 +488,11 @@ template <typename P, bool WIDE> struct LHeap {
 	__device__ __forceinline__ void store_entry(uint32_t st, const LEntry<P> &e) const {
 		uint4 *p = chunk_ptr(st >> 6);
 		const uint32_t fill = st & 63u;
+		const P L = pos_enc<P>(e.L), U = pos_enc<P>(e.U);
 		if (WIDE) {
-			p[fill * 2] = make_uint4((uint32_t)e.L, (uint32_t)((uint64_t)e.L >> 32), (uint32_t)e.U, (uint32_t)((uint64_t)e.U >> 32));
+			p[fill * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
 			p[fill * 2 + 1] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-		} else p[fill] = make_uint4((uint32_t)e.L, (uint32_t)e.U, e.f, pack_w(e.L, e.U, e.sa, e.runsLo));
+		} else p[fill] = make_uint4((uint32_t)L, (uint32_t)U, e.f, pack_w(L, U, e.sa, e.runsLo));
 	}
 	__device__ __forceinline__ void load_entry(uint32_t st, LEntry<P> &e) const {
 		const uint4 *p = chunk_ptr(st >> 6);
@@ -491,11 +501,13 @@ template <typename P, bool WIDE> struct LHeap {
 			const uint4 w0 = p[fill * 2], w1 = p[fill * 2 + 1];
 			e.L = (P)(((uint64_t)w0.y << 32) | w0.x); e.U = (P)(((uint64_t)w0.w << 32) | w0.z);
 			e.f = w1.x; e.sa = w1.y; e.runsLo = w1.z; e.runsHi = w1.w;
+			e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
 		} else {
 			const uint4 w = p[fill];
 			e.L = (P)w.x; e.U = (P)w.y; e.f = w.z; e.sa = w.w & 0x3FFu;
 			if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w.w >> 29) << 32); }
 			e.runsLo = 0xFFFF0000u | ((w.w >> 10) & 0xFFFFu); e.runsHi = 0xFFFFFFFFu;
+			e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
 		}
 	}
 	/* pops the top entry of the cached bucket cb (the best non-empty one) */
@@ -905,6 +917,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 						uint4 *p1 = h.chunk_ptr(st1 >> 6) + ((st1 & 63u) + 1) * ESZ;
 						uint4 *p2 = h.chunk_ptr(st2 >> 6) + ((st2 & 63u) + 1) * ESZ;
 						auto emit = [&](uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+							L = pos_enc<P>(L); U = pos_enc<P>(U);
 							if (WIDE) {
 								p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
 								p[1] = make_uint4(f, sa, (uint32_t)runs, (uint32_t)(runs >> 32));

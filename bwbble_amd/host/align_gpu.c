@@ -78,7 +78,18 @@ static void *gpu_worker(void *arg) {
 		const size_t r0 = c * (size_t)w->chunk;
 		const uint32_t n = (uint32_t)((w->reads->count - r0) < w->chunk ? (w->reads->count - r0) : w->chunk);
 		const int slot = (int)(j % NS);
-		if (bwb_hip_slot_upload(ctx, slot, w->params, w->reads->seq + r0 * w->reads->stride, w->reads->len + r0, n, w->reads->stride) ||
+		/* the last read before this chunk that computes a D_seed (longer than the seed, not dropped by -P): a short read at the
+		 * head of the chunk sees its bounds, like in the reference's serial loop (inexact_match.c:35,62-65) */
+		const uint8_t *carry = NULL;
+		uint32_t carry_len = 0;
+		for (size_t q = r0; q-- > 0 && r0 - q <= 4096;) { /* (bounded look-back; a FASTQ of nothing but short reads has no source anyway) */
+			const uint32_t lq = w->reads->len[q];
+			const uint8_t *sq = w->reads->seq + q * w->reads->stride;
+			int ok = w->params->seed_length && lq > (uint32_t)w->params->seed_length && lq <= 255;
+			if (ok && w->params->use_precalc) { if (lq < 12) ok = 0; for (int k = 0; ok && k < 12; k++) if (sq[k] > 3) ok = 0; }
+			if (ok) { carry = sq; carry_len = lq; break; }
+		}
+		if (bwb_hip_slot_upload(ctx, slot, w->params, w->reads->seq + r0 * w->reads->stride, w->reads->len + r0, n, w->reads->stride, carry, carry_len) ||
 		    bwb_hip_slot_submit(ctx, slot))
 			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
 		in_slot[slot] = c;

@@ -112,10 +112,17 @@ int bwb_hip_reset_stats(bwb_hip_ctx *ctx);
  * next submitted slot's slice, so the heavy tail of one batch overlaps the bulk of the next; slot_wait blocks until every
  * read of the slot is done (launching a draining slice if nothing else is queued); slot_result = slot_wait + D2H of the
  * hits on a result stream, valid until the slot is uploaded again; flush = wait for every slot.  All slots in flight use
- * the same parameters (a slot_upload with different ones flushes first).  Same result bytes as align_batch. */
+ * the same parameters (a slot_upload with different ones flushes first).  Same result bytes as align_batch.
+ *
+ * Reads that are not longer than the seed (len <= seed_length): the reference computes D_seed only for longer reads
+ * (inexact_match.c:62-64) yet inexact_match consults it for every read (:321-328), so its serial path (-t 1) gives a short
+ * read the bounds of the last longer read before it in the file (zeros if there is none; with -t N it depends on the thread
+ * that happens to process the read).  The library reproduces the serial behaviour: inside a batch it knows the order; for
+ * the head of a batch the caller passes that last longer read of the earlier batches as carry_seq/carry_len (read->seq
+ * codes; NULL/0 = none, which is also what batch_upload/align_batch assume). */
 #define BWB_MAX_SLOTS 4
 int bwb_hip_slot_upload(bwb_hip_ctx *ctx, int slot, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
-                        uint32_t n_reads, uint32_t stride);
+                        uint32_t n_reads, uint32_t stride, const uint8_t *carry_seq, uint32_t carry_len);
 int bwb_hip_slot_submit(bwb_hip_ctx *ctx, int slot);
 int bwb_hip_slot_wait(bwb_hip_ctx *ctx, int slot);
 int bwb_hip_slot_result(bwb_hip_ctx *ctx, int slot, bwb_result *out);

@@ -103,7 +103,62 @@ def run(cmd, **kw):
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, **kw)
 
 
+def wgsim_fixture(fq, out):
+    """100 reads of toy.fq in the shape of the reference's own test_data/sim_chr21_N100.fastq (wgsim names with ':' and '/',
+    bare '+' lines) plus what fastq2reads (io.c:410-515) also has to cope with: '+name' lines, lower-case bases, a name with
+    blanks, blank lines between records and no newline at the end of the file."""
+    lines = open(fq).read().split("\n")
+    recs = [lines[i:i + 4] for i in range(0, 400, 4)]
+    o = []
+    for k, (name, seq, _, qual) in enumerate(recs):
+        parts = name[1:].split("_")  # r<k>_chr<c>_<pos>_<strand>
+        pos = int(parts[2])
+        nm = f"{parts[1][3:]}_{pos}_{pos + 500 + k}_{k % 4}:0:0_{k % 3}:0:0_{k:x}/1"
+        if k % 10 == 3:
+            nm += " extra words"
+        if k % 7 == 2:
+            seq = seq.lower()
+        plus = "+" + nm if k % 5 == 1 else "+"
+        o.append(f"@{nm}\n{seq}\n{plus}\n{qual}")
+        if k % 25 == 24:
+            o.append("")
+    open(out, "w").write("\n".join(o))
+
+
+def extras():
+    """Fixtures added in round 2 (kept separate so that they can be regenerated without the 4-minute -P table)."""
+    fa, fq, fq2 = os.path.join(HERE, "toy.fa"), os.path.join(HERE, "toy.fq"), os.path.join(HERE, "ragged.fq")
+    tmp = tempfile.mkdtemp(prefix="bwb_golden_")
+    tfa = os.path.join(tmp, "toy.fa")
+    for ext in ("", ".bwt", ".ann"):
+        import shutil
+        shutil.copy(fa + ext, tfa + ext)
+    # config C5 of BASELINE.json (150 bp reads, -n 5 and the defaults -o 1 -e 6 -l 32 -k 2) on the ragged reads (36..150 bp)
+    run([REF_BIN, "align"] + ALIGN_CONFIGS["n5"] + [tfa, fq2, os.path.join(HERE, "ragged_n5.aln")])
+    # wgsim-shaped FASTQ through the reference's parser, aligner and SAM writer
+    wq = os.path.join(HERE, "wgsim100.fq")
+    wgsim_fixture(fq, wq)
+    run([REF_BIN, "align", "-n", "2", tfa, wq, os.path.join(HERE, "wgsim100_n2.aln")])
+    run([REF_BIN, "aln2sam", tfa, wq, os.path.join(HERE, "wgsim100_n2.aln"), os.path.join(HERE, "wgsim100_n2.sam")])
+    # reads at or below the seed length mixed with longer ones, SERIAL reference (-t 1): a short read sees the D_seed bounds
+    # the last longer read left in the buffer (inexact_match.c:33-35,62-65; SURVEY Appendix B-11)
+    synth = os.path.join(ROOT, "bwbble_amd", "bin", "bwb_synth")
+    parts = []
+    for k, (ln, cnt) in enumerate([(24, 6), (100, 5), (30, 8), (32, 8), (60, 4), (20, 10), (33, 6), (28, 10), (150, 3), (31, 12)]):
+        q = os.path.join(tmp, f"s{k}.fq")
+        run([synth, "reads", fa, q, str(cnt), str(ln), str(300 + k), "3.0", "5.0", "5.0"])
+        parts.append(open(q).read())
+    sq = os.path.join(HERE, "short.fq")
+    open(sq, "w").write("".join(parts))
+    for name, flags in (("n2", ["-n", "2"]), ("n3k1", ["-n", "3", "-k", "1"]), ("p2", ["-P", "-n", "2"])):
+        if "-P" in flags and not os.path.exists(tfa + ".pre"):
+            print("(the reference builds the 74 MB .pre table first: about 4 minutes)")
+        run([REF_BIN, "align"] + flags + ["-t", "1", tfa, sq, os.path.join(HERE, f"short_{name}_t1.aln")])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--extras":
+        return extras()
     if not os.path.isdir(REF_SRC):
         sys.exit("reference sources not present; golden vectors can only be regenerated in the build container")
     run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -177,6 +232,7 @@ def main():
         dpath = os.path.join(tmp, f"d_{tag}.i32")
         run([hbin, "dvec", fa + ".bwt", path, dpath, "32"])
         np.save(os.path.join(HERE, f"dvec_{tag}.npy"), np.fromfile(dpath, dtype=np.int32))
+    extras()
     print("golden vectors written to", HERE)
 
 

@@ -108,8 +108,11 @@ class Oracle:
             raise RuntimeError(f"oracle align failed ({n})")
         return n, st, sec.value
 
-    def align_encoded(self, idx, seqs, lens, p, fresh_dseed=1):
-        """seqs: (n, stride) uint8 codes A0 G1 C2 T3 N4; returns (.aln bytes, Stats, seconds)."""
+    def align_encoded(self, idx, seqs, lens, p, fresh_dseed=0):
+        """seqs: (n, stride) uint8 codes A0 G1 C2 T3 N4; returns (.aln bytes, Stats, seconds).
+        fresh_dseed=0 with p.n_threads <= 1 is the serial reference (one D_seed buffer for the whole file, inexact_match.c:35):
+        a read not longer than the seed sees the bounds of the last longer read before it - what the GPU path reproduces.
+        With threads, every thread has its own buffer over its own share of a 262 144-read batch (:115-121)."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         lens = np.ascontiguousarray(lens, dtype=np.uint16)
         buf, blen, st, sec = C.c_void_p(), C.c_size_t(), Stats(), C.c_double()

@@ -26,7 +26,7 @@ def synth_reads(fa, path, n, length, seed, sub=1.0, indel=0.1, npct=0.0):
     return bw.load_fastq_codes(path)
 
 
-def check(ctx, oracle, idx, flags, seqs, lens, fresh=1):
+def check(ctx, oracle, idx, flags, seqs, lens, fresh=0):
     off, alns = ctx.align(bw.params(flags), seqs, lens)
     want, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags), fresh_dseed=fresh)
     assert bw.aln_bytes(off, alns) == want
@@ -64,7 +64,7 @@ def test_max_entries_break(mid_ctx, oracle):
 
 
 def test_short_and_long_reads(mid_ctx, oracle):
-    """Reads shorter than the seed (D_seed defined as zeros), at the seed length, and 250-base reads."""
+    """Reads shorter than the seed (no longer read before them: D_seed is the calloc'd zeros), at the seed length, and 250-base reads."""
     d, fa, ctx, idx = mid_ctx
     for ln, n in ((20, 400), (32, 400), (33, 400), (250, 300)):
         seqs, lens = synth_reads(fa, str(d / f"l{ln}.fq"), n, ln, 10 + ln, sub=1.0, indel=1.0, npct=3.0)
@@ -230,3 +230,43 @@ def test_random_parameter_sweep(mid_ctx, oracle):
         if rng.random() < 0.25:
             flags.append("-P")
         check(ctx, oracle, idx, flags, seqs, lens)
+
+
+def test_short_reads_inherit_the_last_longer_reads_dseed(mid_ctx, oracle):
+    """Reads <= seed_length mixed with longer ones: D_seed of a short read = that of the last longer read before it (the serial
+    reference's single buffer, inexact_match.c:35,62-65); in one batch, and streamed in small batches with the carried read."""
+    d, fa, ctx, idx = mid_ctx
+    parts = [synth_reads(fa, str(d / f"sh{k}.fq"), cnt, ln, 70 + k, sub=3.0, indel=4.0, npct=4.0)
+             for k, (ln, cnt) in enumerate([(25, 30), (100, 40), (30, 50), (32, 30), (64, 20), (20, 60), (33, 10), (150, 12), (31, 80)])]
+    stride = max(p[0].shape[1] for p in parts)
+    seqs = np.full((sum(len(p[1]) for p in parts), stride), 4, dtype=np.uint8)
+    lens = np.concatenate([p[1] for p in parts])
+    o = 0
+    for s_, l_ in parts:
+        seqs[o:o + len(l_), :s_.shape[1]] = s_
+        o += len(l_)
+    order = np.random.default_rng(3).permutation(len(lens))  # interleave the lengths
+    seqs, lens = seqs[order], lens[order]
+    for flags in (["-n", "2"], ["-n", "3", "-k", "1"], ["-P", "-n", "2"], ["-n", "2", "-l", "64"]):
+        check(ctx, oracle, idx, flags, seqs, lens)
+        fresh, _, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags), fresh_dseed=1)
+        stale, _, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags), fresh_dseed=0)
+        # streamed in batches of 23 reads: the source of a batch's leading short reads lies in an earlier batch (the carry)
+        p = bw.params(flags)
+        sl = p.seed_length
+        got, last = b"", None
+        ctx.flush()
+        for lo in range(0, len(lens), 23):
+            hi = min(lo + 23, len(lens))
+            ctx.slot_upload(0, p, seqs[lo:hi], lens[lo:hi], carry=last)
+            ctx.slot_submit(0)
+            off, alns = ctx.slot_result(0)
+            got += bw.aln_bytes(off, alns)
+            for i in range(lo, hi):
+                ok = lens[i] > sl
+                if ok and p.use_precalc:
+                    ok = not (seqs[i, :12] > 3).any()
+                if ok:
+                    last = seqs[i, :lens[i]].copy()
+        assert got == stale
+    assert fresh != stale  # (the fixture discriminates)

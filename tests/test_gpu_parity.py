@@ -65,6 +65,14 @@ def test_aln_bytes_match_reference_ragged(toy_ctx, golden, name):
     assert bw.aln_bytes(off, alns) == open(os.path.join(golden, f"ragged_{name}.aln"), "rb").read()
 
 
+@pytest.mark.parametrize("name,flags", [("n2", ["-n", "2"]), ("n3k1", ["-n", "3", "-k", "1"]), ("p2", ["-P", "-n", "2"])])
+def test_short_reads_match_serial_reference(toy_ctx, golden, name, flags):
+    """reads <= seed_length between longer ones: the bytes of the reference's serial path (-t 1), SURVEY Appendix B-11"""
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "short.fq")))
+    off, alns = toy_ctx.align(bw.params(flags), seqs, lens)
+    assert bw.aln_bytes(off, alns) == open(os.path.join(golden, f"short_{name}_t1.aln"), "rb").read()
+
+
 @pytest.mark.parametrize("name", ["n0", "n3"])
 def test_work_counters_match_oracle(toy_ctx, oracle, golden, name):
     """The visit counts that feed roofline.achieved are the SURVEY 8(d) algorithmic counts."""

@@ -179,3 +179,28 @@ def test_index_long_repeats_match_reference(built, tmp_path):
         run([ref_bin, "index", str(fb)])
         assert open(str(fb) + ".bwt", "rb").read() == data
         assert open(str(fb) + ".ann", "rb").read() == open(str(fa) + ".ann", "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_wgsim_shaped_fastq(toy_dir, golden):
+    """FASTQ in the shape of the reference's test_data/sim_chr21_N100.fastq (wgsim names, bare '+' lines) plus '+name' lines,
+    lower-case bases, names with blanks, blank lines and no final newline: host/reads.c against the reference's fastq2reads
+    (io.c:410-515) through align and aln2sam - names, sequences and qualities all end up in the SAM text."""
+    aln, sam = toy_dir / "w.aln", toy_dir / "w.sam"
+    fq = os.path.join(golden, "wgsim100.fq")
+    log = run([bw.HOST_BIN, "align", "-n", "2", str(toy_dir / "toy.fa"), fq, str(aln)])
+    assert "Processed 100 reads" in log
+    assert open(aln, "rb").read() == open(os.path.join(golden, "wgsim100_n2.aln"), "rb").read()
+    run([bw.HOST_BIN, "aln2sam", str(toy_dir / "toy.fa"), fq, str(aln), str(sam)])
+    assert open(sam).read() == open(os.path.join(golden, "wgsim100_n2.sam")).read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", ["1000000", "7"])
+def test_cli_short_reads_match_serial_reference(toy_dir, golden, chunk):
+    """the CLI on short.fq, in one chunk and in chunks of 7 reads (the D_seed source of a chunk's first short reads is carried over)"""
+    out = toy_dir / f"short{chunk}.aln"
+    env = dict(os.environ, BWB_CHUNK=chunk)
+    subprocess.run([bw.HOST_BIN, "align", "-n", "3", "-k", "1", str(toy_dir / "toy.fa"), os.path.join(golden, "short.fq"), str(out)],
+                   check=True, env=env, stdout=subprocess.DEVNULL)
+    assert open(out, "rb").read() == open(os.path.join(golden, "short_n3k1_t1.aln"), "rb").read()

@@ -55,7 +55,7 @@ def test_aln_bytes_match_reference(oracle, golden, tmp_path, name):
     assert open(out, "rb").read() == open(os.path.join(golden, f"toy_{name}.aln"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2", "p2"])
+@pytest.mark.parametrize("name", ["n0", "n3", "n4gap", "s2", "p2", "n5"])
 @pytest.mark.parametrize("threads", [1, 3])
 def test_ragged_reads_match_reference(oracle, golden, tmp_path, name, threads):
     out = str(tmp_path / "o.aln")
@@ -63,3 +63,16 @@ def test_ragged_reads_match_reference(oracle, golden, tmp_path, name, threads):
     n, _, _ = oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "ragged.fq"), out, p)
     assert n == 200
     assert open(out, "rb").read() == open(os.path.join(golden, f"ragged_{name}.aln"), "rb").read()
+
+
+@pytest.mark.parametrize("name,flags", [("n2", ["-n", "2"]), ("n3k1", ["-n", "3", "-k", "1"]), ("p2", ["-P", "-n", "2"])])
+def test_short_reads_see_the_previous_long_reads_dseed(oracle, golden, tmp_path, name, flags):
+    """short.fq mixes reads <= seed_length with longer ones; the reference was run with -t 1 (serial: one D_seed buffer for the
+    whole file, inexact_match.c:35).  The oracle's serial mode must give those bytes; zeroing D_seed per read must not."""
+    out = str(tmp_path / "o.aln")
+    want = open(os.path.join(golden, f"short_{name}_t1.aln"), "rb").read()
+    p = oracle.params(flags + ["-t", "1"])
+    oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "short.fq"), out, p, fresh_dseed=0)
+    assert open(out, "rb").read() == want
+    oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "short.fq"), out, p, fresh_dseed=1)
+    assert open(out, "rb").read() != want
