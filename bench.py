@@ -109,9 +109,12 @@ def main():
 
     import torch  # plumbing only (device census, barrier, max-over-ranks)
     from bwbble_amd import dist as bdist
-    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
-        sys.exit(f"bench.py: rank {rank} needs HIP device {local_rank}, {torch.cuda.device_count()} visible (no CPU path)")
-    grp = bdist.Group()  # one process per GPU; backend nccl (= RCCL) when launched by torch.distributed.run
+    ndev = torch.cuda.device_count()
+    share = bool(os.environ.get("BWB_BENCH_SHARE_DEVICE"))  # test knob: several ranks on one GPU (gloo for the timing protocol)
+    device = local_rank % max(ndev, 1) if share else local_rank
+    if ndev < device + 1:
+        sys.exit(f"bench.py: rank {rank} needs HIP device {device}, {ndev} visible (no CPU path)")
+    grp = bdist.Group(backend="gloo" if share and world > 1 else None)  # one process per GPU; nccl (= RCCL) under torch.distributed.run
     barrier = grp.barrier
     for r in range(world):  # every shard exists before anybody needs a neighbour's
         wait_for(os.path.join(a.workdir, f"reads_{n_fwd}_{a.pool}_{a.read_len}_r{r}.fq.ok"), f"rank {r}'s FASTQ shard")
@@ -121,7 +124,7 @@ def main():
     p = bw.params(flags)
     bwt = bw.BwtFile(fa + ".bwt")
     t0 = time.time()
-    ctx = bw.Context(bwt, device=local_rank)
+    ctx = bw.Context(bwt, device=device)
     t_ctx = time.time() - t0
     B = a.reads
     nb = max(1, min(bw.MAX_SLOTS, a.pool // B))  # batches resident in HBM; step s runs batch s % nb
@@ -195,15 +198,16 @@ def main():
     if os.path.exists(prof):
         pj = json.load(open(prof))
         if (pj.get("genome_mb"), pj.get("reads"), pj.get("ndiff")) == (a.genome_mb, B, a.ndiff) and dom_name in pj:
-            traffic = pj[dom_name]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r2_c3_pmc.json: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), bytes per launch; NOT measured in this run"
+            traffic = pj[dom_name]["hbm_bytes_per_step"] * a.steps / max(dom["launches"], 1)
+            traffic_src = ("profiles/r2_c3_pmc.json: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), "
+                           "HBM bytes per step there x steps / launches here = bytes per launch; NOT measured in this run")
     index_mb = bwt.length / 1e6  # one 128-byte bucket per 128 BWT characters
     scale = {3_100_000_000: "C3 GRCh37-scale", 48_000_000: "C2 chr21-scale"}.get(n_fwd, f"{n_fwd / 1e6:.0f} M-char")
     residency = (f"device index {index_mb:.0f} MB: Infinity-Cache (256 MB) resident, so this is the fraction of the HBM peak reached from cache"
                  if index_mb <= 256 else f"device index {index_mb:.0f} MB: larger than the 256 MB Infinity Cache, bucket loads come from HBM")
     out = {
         "metric": "100bp reads aligned/sec (inexact BWT backward search, IUPAC FM-index)", "value": round(value, 1), "unit": "reads/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "n_gpus": world if not share else len({r % max(ndev, 1) for r in range(world)}), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if bwt.length < 0xFFFFFFFF else "u64", "data": "synthetic",
         "config": {"workload": f"{scale} synthetic multi-genome: {n_fwd} fwd chars (BWT length {bwt.length}), FASTQ shard of {a.pool} x {a.read_len} bp "
                                f"reads per GPU, one step = one resident batch of {B} reads (step s runs batch s mod {nb}), align -n {a.ndiff} (other params default)",

@@ -252,7 +252,8 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 }
 
 static size_t lane_lds(const bwb_hip_ctx *c) {
-	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)2 * KID_ROWS * LANE_BLOCK * (c->pos32 ? 4 : 8);
+	(void)c;
+	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)(LANE_BLOCK / 64) * WAVE_LDS_BYTES; /* base table + per wave: gather staging / children */
 }
 
 static uint32_t max_reads_resident(const bwb_hip_ctx *c) {
@@ -450,7 +451,7 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 		if (bad) { n_bad++; continue; }
 		maxlen = std::max<uint32_t>(maxlen, lens[i]);
 		if (is_source(reads_fwd + (size_t)i * stride, lens[i])) last = i;
-		else if (sl && lens[i] && lens[i] <= sl && last != NONE32) {
+		else if (sl && lens[i] <= sl && last != NONE32) {
 			if (!s.inherit) { s.h_src.assign(n_reads, NONE32); s.inherit = true; }
 			s.h_src[i] = last;
 		}
@@ -487,7 +488,7 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	else
 		for (uint32_t i = 0; i < n_reads; i++) {
 			const bool bad = lens[i] > 255 || lens[i] > stride || (p->use_precalc && lens[i] < PRECALC_LEN);
-			hl[i] = bad ? 0 : lens[i];
+			hl[i] = bad ? (uint16_t)BAD_LEN : lens[i];
 			memcpy(hr + (size_t)i * s.stride, reads_fwd + (size_t)i * stride, bad ? 0 : lens[i]);
 		}
 	if (s.n_tot > n_reads) { hl[n_reads] = (uint16_t)carry_len; memcpy(hr + (size_t)n_reads * s.stride, carry_seq, carry_len); }

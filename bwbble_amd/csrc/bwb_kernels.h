@@ -14,6 +14,7 @@
 #define BWB_BLOCK 256
 #define BWB_OCTS_PER_BLOCK 32
 #define NONE32 0xFFFFFFFFu
+#define BAD_LEN 0xFFFFu   /* lens[] marker of a read the kernels cannot represent (> 255 bases; < 12 with -P): it gets an empty record */
 #define ST_OK 0
 #define ST_SCRATCH_OVF 1  /* heap arena / interval list / hit list too small: re-run in a bigger class */
 #define ST_OUT_OVF 2      /* the slot's hit log is full: host grows it and re-runs the read */
@@ -198,7 +199,7 @@ __global__ void k_dseed_inherit(Batch b, const uint32_t *src, uint32_t n) {
 	const int lr = b.lens[r], lq = b.lens[q];
 	uint8_t *rr = b.dbuf + (size_t)r * b.dstride;
 	const uint8_t *rq = b.dbuf + (size_t)q * b.dstride;
-	for (int i = 1; i <= lr; i++) *(uint16_t *)(rr + 8 * i + 2) = *(const uint16_t *)(rq + 8 * (i + lq - lr) + 2);
+	for (int i = 0; i <= lr; i++) /* (i = 0: the hit check of a read shorter than the seed) */ *(uint16_t *)(rr + 8 * i + 2) = *(const uint16_t *)(rq + 8 * (i + lq - lr) + 2);
 }
 
 /* SA[row] by the invPsi walk (bwt.c:311-329): one octet per row */

@@ -30,6 +30,10 @@
 #include "bwb_kernels.h"
 
 #define LANE_BLOCK 256
+#define KID_STRIDE 64            /* children live in LDS columns of the lane's own wave: child j of lane o at [j * 64 + o] */
+/* LDS of a wave: the staging area of the cooperative bucket gather (2 sides x 64 buckets x 128 bytes), re-used for the children
+ * once the buckets are in registers (2 x 16 rows x 64 lanes x 4 or 8 bytes <= 16 KB) */
+#define WAVE_LDS_BYTES (2 * 64 * 128)
 /* lane-private LDS columns: explicit LDS address space, so they compile to ds_read/ds_write (a generic or volatile
  * pointer here turns every access into a flat_* instruction with 64-bit addresses and full waits) */
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
@@ -67,40 +71,56 @@ template <typename P> struct LaneReq {
 	uint4 d[8];
 };
 
-template <typename P>
-__device__ __forceinline__ void lane_issue(const uint4 *__restrict__ buckets, P last_row, P pos, LaneReq<P> &r) {
-	r.pos = pos;
-	const bool neg = (pos == (P)~(P)0), end = (pos == last_row);
-	r.regular = !(neg || end);
-	const P blk = pos >> 7;
-	r.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BWB_SB_SHIFT));
-	const uint4 *b = buckets + (size_t)(r.regular ? blk : 0) * 8;
-#pragma unroll
-	for (int k = 0; k < 8; k++) r.d[k] = b[k];
-}
+/* Cooperative gather: one 128-byte bucket per lane, loaded by the whole wave.  Instruction r fetches the buckets of lanes
+ * 8r .. 8r+7: lane l loads slice (l & 7) of the bucket of lane 8r + (l >> 3), so a wave instruction touches 8 lines of
+ * 128 contiguous bytes instead of 64 different ones, and the slices reach their owner through the wave's LDS staging area.
+ * Measured on a 7 GiB table (tools_exp/gather_bench.hip, profiles/r2_gather_shape.txt): 50 G buckets/s (6.4 TB/s) this
+ * way against 10.9 G/s (1.4 TB/s) when every lane loads its own bucket with 8 x dwordx4 - at GRCh37 scale the per-lane shape is
+ * bound by address translation, 64 different pages per instruction, not by HBM.  Called by EVERY lane of the wave
+ * (blk == NONE32: this lane wants nothing; it still loads for the others). */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
 
-/* both sides of an SA interval: when L-1 and U fall into the same bucket (narrow intervals: most of them) the second
- * gather is skipped and the registers are copied */
+/* Both sides of an SA interval for every lane of the wave.  `need`: this lane wants a rank at pL and pU.  When L-1 and U fall
+ * into the same bucket (narrow intervals: most of them) it is fetched once.  Returns the number of buckets fetched for this
+ * lane.
+ * The 16 loads (8 rounds x 2 sides) are global_load_lds_dwordx4: memory -> LDS without a register in between, all in flight
+ * together.  Such a load writes LDS at base + 16 * lane, so round r fills 1 KB = rows of the owners 8r .. 8r+7; to keep the
+ * owners' 128-bit reads off each other's banks the slices of owner o are rotated by (o >> 1) & 7 - on the SOURCE side (the lane
+ * at position p of owner o's row loads slice (p - rot) & 7), which is the only side such a load lets one choose.
+ * The staging area is free again (for the children) when this returns. */
 template <typename P>
-__device__ __forceinline__ uint32_t lane_issue_pair(const uint4 *__restrict__ buckets, P last_row, P pL, P pU, LaneReq<P> &ra, LaneReq<P> &rb) {
-	lane_issue<P>(buckets, last_row, pL, ra);
-	rb.pos = pU;
-	const bool neg = (pU == (P)~(P)0), end = (pU == last_row);
-	rb.regular = !(neg || end);
-	const P blk = pU >> 7;
-	rb.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BWB_SB_SHIFT));
-	const bool same = ra.regular && rb.regular && (pL >> 7) == blk;
-	const uint4 *b = buckets + (size_t)(rb.regular ? blk : 0) * 8;
-	uint4 t[8];
+__device__ __forceinline__ uint32_t wave_fetch_pair(const uint4 *__restrict__ buckets, P last_row, bool need, P pL, P pU, LaneReq<P> &ra, LaneReq<P> &rb,
+                                                    Lds<u32x4> stage, int lane) {
+	ra.pos = pL; rb.pos = pU;
+	const bool negL = (pL == (P)~(P)0), endL = (pL == last_row), negU = (pU == (P)~(P)0), endU = (pU == last_row);
+	ra.regular = !(negL || endL); rb.regular = !(negU || endU);
+	const P blkL = pL >> 7, blkU = pU >> 7;
+	ra.row = negL ? BWB_ROW_NEG : (endL ? BWB_ROW_END : (int)((uint64_t)blkL >> BWB_SB_SHIFT));
+	rb.row = negU ? BWB_ROW_NEG : (endU ? BWB_ROW_END : (int)((uint64_t)blkU >> BWB_SB_SHIFT));
+	const bool same = ra.regular && rb.regular && blkL == blkU;
+	const bool wantL = need && ra.regular, wantU = need && rb.regular && !same;
+	const uint32_t myL = wantL ? (uint32_t)blkL : NONE32, myU = wantU ? (uint32_t)blkU : NONE32; /* (block numbers fit 32 bits: 2^34 characters / 128) */
+	const int sub = lane >> 3, p = lane & 7;
+	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the children of the previous iteration (same LDS) have been read */
+	uint32_t oL[8], oU[8]; /* the 16 exchanges first (one wait), then the 16 loads back to back */
 #pragma unroll
-	for (int k = 0; k < 8; k++) t[k] = ra.d[k];
-	if (!same) {
+	for (int r = 0; r < 8; r++) { oL[r] = (uint32_t)__shfl((int)myL, 8 * r + sub); oU[r] = (uint32_t)__shfl((int)myU, 8 * r + sub); }
 #pragma unroll
-		for (int k = 0; k < 8; k++) t[k] = b[k];
+	for (int r = 0; r < 8; r++) {
+		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
+		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oL[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 64 * r), 16, 0, 0);
+		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oU[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 512 + 64 * r), 16, 0, 0);
 	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the slices have landed in LDS */
+	__builtin_amdgcn_wave_barrier();
+	const int rot = lane >> 1;
+	const Lds<u32x4> mineL = stage + lane * 8, mineU = mineL + 512;
 #pragma unroll
-	for (int k = 0; k < 8; k++) rb.d[k] = t[k];
-	return (ra.regular ? 1u : 0u) + ((rb.regular && !same) ? 1u : 0u); /* 128-byte buckets actually fetched */
+	for (int k = 0; k < 8; k++) { u32x4 v = (u32x4)(0u); if (wantL) v = mineL[(k + rot) & 7]; ra.d[k] = make_uint4(v.x, v.y, v.z, v.w); }
+#pragma unroll
+	for (int k = 0; k < 8; k++) { uint4 w = ra.d[k]; if (wantU) { const u32x4 v = mineU[(k + rot) & 7]; w = make_uint4(v.x, v.y, v.z, v.w); } rb.d[k] = w; }
+	__builtin_amdgcn_s_waitcnt(0xc07f); /* the buckets are in registers before the children overwrite the staging area */
+	return (wantL ? 1u : 0u) + (wantU ? 1u : 0u);
 }
 
 /* pop[j] = #j in the bucket's block at offsets [0, pos & 127], j = 1..15 */
@@ -155,7 +175,7 @@ __device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb
 		for (int j = 1; j < 16; j++) {
 			P v = lane_val<P>(ra, brow, pop, j);
 			if (j == 5 || j == 9 || j == 11 || j == 13) v = q ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : v;
-			kidL[j * LANE_BLOCK] = v + 1;
+			kidL[j * KID_STRIDE] = v + 1;
 		}
 	}
 	uint32_t ne = 0;
@@ -168,8 +188,8 @@ __device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb
 		for (int j = 1; j < 16; j++) {
 			P U = lane_val<P>(rb, brow, pop, j);
 			if (j == 5 || j == 9 || j == 11 || j == 13) U = q ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : U;
-			kidU[j * LANE_BLOCK] = U;
-			ne |= (kidL[j * LANE_BLOCK] <= U ? 1u : 0u) << j;
+			kidU[j * KID_STRIDE] = U;
+			ne |= (kidL[j * KID_STRIDE] <= U ? 1u : 0u) << j;
 		}
 	}
 	return ne;
@@ -199,8 +219,7 @@ __device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buck
 	uint32_t fL = 0, fU = 0;
 	rank_finish<P, false>(ra, s_base, ol, lane, a0, a1, &fL);
 	rank_finish<P, false>(rb, s_base, ol, lane, u0, u1, &fU);
-	const int col = (int)(threadIdx.x & ~63u) + o;
-	Lds<P> kL = kids + col, kU = kids + KID_ROWS * LANE_BLOCK + col;
+	Lds<P> kL = kids + o, kU = kids + KID_ROWS * KID_STRIDE + o; /* the owner's columns (kids = this wave's area) */
 	const int j0 = 2 * ol, j1 = 2 * ol + 1;
 	if (oalpha && (j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13)) { /* O_alphabet's view of the uncounted codes */
 		const P cn = s_base[BWB_ROW_NEG * 16 + j1];
@@ -210,8 +229,8 @@ __device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buck
 	const P L0 = a0 + 1, L1 = a1 + 1;
 	uint32_t bits = 0;
 	if (valid) {
-		if (j0 >= 1) { kL[j0 * LANE_BLOCK] = L0; kU[j0 * LANE_BLOCK] = u0; bits |= (L0 <= u0 ? 1u : 0u) << j0; }
-		kL[j1 * LANE_BLOCK] = L1; kU[j1 * LANE_BLOCK] = u1;
+		if (j0 >= 1) { kL[j0 * KID_STRIDE] = L0; kU[j0 * KID_STRIDE] = u0; bits |= (L0 <= u0 ? 1u : 0u) << j0; }
+		kL[j1 * KID_STRIDE] = L1; kU[j1 * KID_STRIDE] = u1;
 		bits |= (L1 <= u1 ? 1u : 0u) << j1;
 	}
 	bits = oct_or(bits);
@@ -250,9 +269,12 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
                                                         uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
-	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
+	const int lane = (int)(threadIdx.x & 63u);
+	unsigned char __attribute__((address_space(3))) *wlds = (unsigned char __attribute__((address_space(3))) *)(smem + BWB_BASE_ROWS * 16 * 8) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
+	Lds<u32x4> stage = (Lds<u32x4>)wlds;
+	Lds<P> kids = (Lds<P>)wlds;
 	load_base<P>(s_base, ix);
-	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
+	Lds<P> kidL = kids + lane, kidU = kids + KID_ROWS * KID_STRIDE + lane;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	Intv<P> *lbase = (Intv<P> *)sc.lists_d + (size_t)slot * 2 * sc.lcap;
 	const int cap = (int)sc.lcap;
@@ -276,6 +298,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			if (rid == NONE32) done = true;
 			else {
 				len = b.lens[rid];
+				const bool unrep = len == BAD_LEN; /* a read the kernels cannot represent (host: slot_upload): empty record */
+				if (unrep) len = 0;
 				r_vis = 0;
 				seq = b.reads + (size_t)rid * b.stride;
 				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads
 					 * whatever its thread's buffer holds.  We define that as the calloc'd zeros (num_diff 0, equal widths). */
 					uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
-					for (int i = 1; i <= len; i++) {
+					for (int i = 0; i <= len; i++) { /* (i = 0: the hit check of a read shorter than the seed consults D_seed too, :324-328) */
 						const int si = i - (len - kp.seed_length);
 						*(uint16_t *)(rec + 8 * i + 2) = (uint16_t)((si >= 1 ? 0x80u : 0u) | (si >= 2 ? 0x8000u : 0u));
 					}
@@ -297,23 +321,29 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			}
 		}
 		if (__all(done)) break;
+		int c = 4;
+		P iL = 0, iU = 0;
+		if (active) {
+			c = seq[r];
+			if (c > 3 && phase == 0) cntN++;
+			if (c <= 3) {
+				if (s == curT - 1) { iL = cL; iU = cU; }
+				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
+			}
+		}
+		const bool need = active && c <= 3;
+		LaneReq<P> ra, rb;
+		n_bkt += wave_fetch_pair<P>(buckets, last_row, need, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
 		if (!active) continue;
-		const int c = seq[r];
 		bool ovf = false;
-		if (c > 3 && phase == 0) cntN++;
 		if (c <= 3) {
-			P iL, iU;
-			if (s == curT - 1) { iL = cL; iU = cU; }
-			else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
-			LaneReq<P> ra, rb;
-			n_bkt += lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
 			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
 			uint32_t ne = lane_children<P>(ra, rb, s_base, false, kidL, kidU);
 			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
 			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
 				const int j = __ffs((int)ne) - 1;
 				ne &= ne - 1;
-				const P L = kidL[j * LANE_BLOCK], U = kidU[j * LANE_BLOCK];
+				const P L = kidL[j * KID_STRIDE], U = kidU[j * KID_STRIDE];
 				nm += (int32_t)(uint32_t)(U - L + 1);
 				list_add<P>(nx, L, U, cap, ovf);
 			}
@@ -549,7 +579,10 @@ template <typename P, bool WIDE>
 __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
-	Lds<P> kids = (Lds<P>)(smem + BWB_BASE_ROWS * 16 * 8);
+	const int lane = (int)(threadIdx.x & 63u);
+	unsigned char __attribute__((address_space(3))) *wlds = (unsigned char __attribute__((address_space(3))) *)(smem + BWB_BASE_ROWS * 16 * 8) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
+	Lds<u32x4> stage = (Lds<u32x4>)wlds;
+	Lds<P> kids = (Lds<P>)wlds; /* this wave's children; the same LDS as the staging area of the gather, one after the other */
 	__shared__ unsigned long long s_blockfree;
 	__shared__ unsigned int s_active, s_nfree, s_left; /* reads in flight in this block; chunks on its recycle stack; waves that have left */
 	if (threadIdx.x == 0) {
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		s_active = 0; s_left = 0;
 	}
 	load_base<P>(s_base, ix);
-	Lds<P> kidL = kids + threadIdx.x, kidU = kids + KID_ROWS * LANE_BLOCK + threadIdx.x;
+	Lds<P> kidL = kids + lane, kidU = kids + KID_ROWS * KID_STRIDE + lane;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
 	uint4 *myalns = sc.alns + (size_t)slot * sc.acap * 2;
@@ -658,6 +691,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				r_vis_s = r_vis_a = r_pop = r_push = 0; r_iter = 0;
 				len = b.lens[rid];
+				const bool unrep = len == BAD_LEN;
+				if (unrep) len = 0;
 				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
 				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
@@ -666,7 +701,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				bool ovf0 = false;
 				/* a read whose calculate_d overflowed its scratch class waits for the re-run of both kernels in a larger class */
 				const bool dfail = b.status[rid] == ST_D_OVF;
-				bool skip = cntN > kp.max_diff || len == 0 || dfail; /* inexact_match.c:260-266 */
+				/* (an EMPTY read is searched like any other: its root entry is a hit with the whole index as its interval, :331-344) */
+				bool skip = cntN > kp.max_diff || unrep || dfail; /* inexact_match.c:260-266 */
 				seeding = false; r_stop = 0;
 				if (kp.use_precalc && !skip) {
 					/* -P.  A read with an N in the last 12 bases of rc (= the first 12 of seq) gets an empty record
@@ -791,7 +827,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		uint32_t stX = NONE32, stG = NONE32;
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
-		if (need_rank) {
+		if (need_rank || (from_pop && len < kp.seed_length)) { /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
 			const uint2 rec = recs[widx]; /* one load: D[i-1], D[i-2] | D_seed pair | seq[len - widx] */
 			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
 			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
@@ -801,19 +837,17 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				stG = h.bstate[scG < nb ? scG : nb - 1];
 			}
 			const P pl = (P)(iL - 1);
-			nvis = ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
+			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
 		}
 		STAMP(2);
 		if (nreq > COOP_MAX_REQ) {
-			if (need_rank) {
-				LaneReq<P> ra, rb;
-				n_bkt += lane_issue_pair<P>(buckets, last_row, (P)(iL - 1), iU, ra, rb);
-				ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
-			}
+			LaneReq<P> ra, rb;
+			n_bkt += wave_fetch_pair<P>(buckets, last_row, need_rank, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
+			if (need_rank) ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
 		} else if (nreq > 0) {
 			unsigned long long rm = rmask;
 			for (int base = 0; base < nreq; base += 8) {
-				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, alpha, iL, iU, kids, (int)(threadIdx.x & 63u));
+				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, alpha, iL, iU, kids, lane);
 				for (int t = 0; t < 8; t++) rm &= rm - 1;
 			}
 			n_bkt += (uint32_t)nvis; /* the octet path fetches both buckets of a pair (counted in the owner lane) */
@@ -821,10 +855,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		if (!kp.multiref && need_rank) {
 			/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with
 			 * alphabet_size 5): move codes 15, 3, 7, 1 to rows 1..4 */
-			const P a0 = kidL[15 * LANE_BLOCK], a1 = kidU[15 * LANE_BLOCK], g0 = kidL[3 * LANE_BLOCK], g1 = kidU[3 * LANE_BLOCK];
-			const P c0 = kidL[7 * LANE_BLOCK], c1 = kidU[7 * LANE_BLOCK], t0 = kidL[1 * LANE_BLOCK], t1 = kidU[1 * LANE_BLOCK];
-			kidL[1 * LANE_BLOCK] = a0; kidU[1 * LANE_BLOCK] = a1; kidL[2 * LANE_BLOCK] = g0; kidU[2 * LANE_BLOCK] = g1;
-			kidL[3 * LANE_BLOCK] = c0; kidU[3 * LANE_BLOCK] = c1; kidL[4 * LANE_BLOCK] = t0; kidU[4 * LANE_BLOCK] = t1;
+			const P a0 = kidL[15 * KID_STRIDE], a1 = kidU[15 * KID_STRIDE], g0 = kidL[3 * KID_STRIDE], g1 = kidU[3 * KID_STRIDE];
+			const P c0 = kidL[7 * KID_STRIDE], c1 = kidU[7 * KID_STRIDE], t0 = kidL[1 * KID_STRIDE], t1 = kidU[1 * KID_STRIDE];
+			kidL[1 * KID_STRIDE] = a0; kidU[1 * KID_STRIDE] = a1; kidL[2 * KID_STRIDE] = g0; kidU[2 * KID_STRIDE] = g1;
+			kidL[3 * KID_STRIDE] = c0; kidU[3 * KID_STRIDE] = c1; kidL[4 * KID_STRIDE] = t0; kidU[4 * KID_STRIDE] = t1;
 			ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
 		}
 		STAMP(3);
@@ -934,7 +968,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 							while (gm) {
 								const int j = __ffs((int)gm) - 1;
 								gm &= gm - 1;
-								emit(pg, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], fd, sd, gruns_d);
+								emit(pg, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], fd, sd, gruns_d);
 							}
 							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
 						}
@@ -946,14 +980,14 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 							while (xm) {
 								const int j = __ffs((int)xm) - 1;
 								xm &= xm - 1;
-								emit(px, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], f_mis, sm, eruns);
+								emit(px, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], f_mis, sm, eruns);
 							}
 							if (tX == 1) p1 = px; else p0 = px;
 							uint32_t mm = matchm;
 							while (mm) {
 								const int j = __ffs((int)mm) - 1;
 								mm &= mm - 1;
-								h.top.L = kidL[j * LANE_BLOCK]; h.top.U = kidU[j * LANE_BLOCK];
+								h.top.L = kidL[j * KID_STRIDE]; h.top.U = kidU[j * KID_STRIDE];
 								emit(p0, h.top.L, h.top.U, f_match, sm, eruns);
 							}
 							if (matchm) { h.top.f = f_match; h.top.sa = sm; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi; top_ok = true; }
@@ -962,7 +996,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 							while (am) {
 								const int j = __ffs((int)am) - 1;
 								am &= am - 1;
-								emit(p0, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
+								emit(p0, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
 							}
 						}
 						STAMP(13);
@@ -985,7 +1019,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;
-					list_add<P>(nx, kidL[j * LANE_BLOCK], kidU[j * LANE_BLOCK], lcap, ovf);
+					list_add<P>(nx, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], lcap, ovf);
 				}
 				s++;
 				if (!ovf && s >= curT) {
@@ -1100,31 +1134,32 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	}
 }
 
-/* Rank micro-benchmark, lane layout: one query per lane (8 x global_load_dwordx4 of one 128-byte bucket, 64 different buckets
- * per wave instruction), two queries in flight per lane, all 15 codes ranked - the access pattern and the ALU work of a rank
- * visit in kl_search / kl_calc_d without anything else.  Same queries and same checksum as k_rank_bench (octet layout). */
+/* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_fetch_pair, one
+ * side only) and every lane ranks all 15 codes of its own bucket: the access pattern and the ALU work of a rank visit in
+ * kl_search / kl_calc_d without anything else.  Same queries and same checksum as k_rank_bench (octet layout). */
 template <typename P>
 __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uint64_t n, uint64_t seed, unsigned long long *checksum) {
 	__shared__ P s_base[BWB_BASE_ROWS * 16];
+	__shared__ u32x4 s_stage[LANE_BLOCK / 64][2 * 64 * 8];
 	load_base<P>(s_base, ix);
 	const uint64_t nl = (uint64_t)gridDim.x * LANE_BLOCK;
+	const int lane = (int)(threadIdx.x & 63u);
+	Lds<u32x4> stage = (Lds<u32x4>)&s_stage[threadIdx.x >> 6][0];
 	const P last_row = (P)(ix.length - 1);
 	unsigned long long acc = 0;
-	for (uint64_t q = ((uint64_t)blockIdx.x * LANE_BLOCK + threadIdx.x) * 2; q < n; q += nl * 2) {
-		LaneReq<P> rq[2];
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			uint64_t x = (q + u) * 0x9E3779B97F4A7C15ull + seed;
-			x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
-			lane_issue<P>(ix.buckets, last_row, (P)(x % (ix.length - 1)), rq[u]);
-		}
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
+	const uint64_t n_round = (n + nl - 1) / nl * nl; /* whole waves iterate together */
+	for (uint64_t q = (uint64_t)blockIdx.x * LANE_BLOCK + threadIdx.x; q < n_round; q += nl) {
+		uint64_t x = q * 0x9E3779B97F4A7C15ull + seed;
+		x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+		const P pos = (P)(x % (ix.length - 1));
+		LaneReq<P> ra, rb;
+		wave_fetch_pair<P>(ix.buckets, last_row, q < n, pos, pos, ra, rb, stage, lane);
+		if (q < n) {
 			uint32_t pop[16];
-			lane_pops<P>(rq[u], pop);
-			const P *brow = s_base + rq[u].row * 16;
+			lane_pops<P>(ra, pop);
+			const P *brow = s_base + ra.row * 16;
 #pragma unroll
-			for (int j = 1; j < 16; j++) acc += (unsigned long long)lane_val<P>(rq[u], brow, pop, j) * ((j & 1) ? 3ull : 1ull);
+			for (int j = 1; j < 16; j++) acc += (unsigned long long)lane_val<P>(ra, brow, pop, j) * ((j & 1) ? 3ull : 1ull);
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

@@ -158,27 +158,34 @@ def test_streamed_slots_match_oracle(mid_ctx, oracle):
 
 
 def test_unrepresentable_reads_get_empty_records(mid_ctx, oracle):
-    """A read longer than 255 bases (aln_entry_t.i is 8-bit, align.h:104) no longer fails the batch: empty record, the others exact."""
+    """A read longer than 255 bases (aln_entry_t.i is 8-bit, align.h:104) no longer fails the batch: empty record, the others
+    exact.  (An EMPTY read is different: like in the reference its root entry is a hit with the whole index as interval.)"""
     d, fa, ctx, idx = mid_ctx
     seqs, lens = synth_reads(fa, str(d / "u.fq"), 300, 100, 33)
+    empty = (0).to_bytes(4, "little")
+
+    def want_with_hole(flags, hole):
+        a, _, _ = oracle.align_encoded(idx, seqs[:hole], lens[:hole], oracle.params(flags))
+        b, _, _ = oracle.align_encoded(idx, seqs[hole + 1:], lens[hole + 1:], oracle.params(flags))
+        return a + empty + b
+
     big = np.full((len(lens), 300), 4, dtype=np.uint8)
     big[:, :100] = seqs
     lens2 = lens.copy()
     lens2[7] = 300
     big[7, :] = 0
     off, alns = ctx.align(bw.params(["-n", "2"]), big, lens2)
-    lens3 = lens.copy()
-    lens3[7] = 0
-    want, _, _ = oracle.align_encoded(idx, seqs, lens3, oracle.params(["-n", "2"]))
-    assert bw.aln_bytes(off, alns) == want
+    assert bw.aln_bytes(off, alns) == want_with_hole(["-n", "2"], 7)
     # -P with a read shorter than 12 bases: the same
     lens4 = lens.copy()
     lens4[3] = 11
     off, alns = ctx.align(bw.params(["-P", "-n", "1"]), seqs, lens4)
-    lens5 = lens4.copy()
-    lens5[3] = 0
-    want, _, _ = oracle.align_encoded(idx, seqs, lens5, oracle.params(["-P", "-n", "1"]))
-    assert bw.aln_bytes(off, alns) == want
+    assert bw.aln_bytes(off, alns) == want_with_hole(["-P", "-n", "1"], 3)
+    # an empty read, and one of a single base: whatever the reference does with them (here: the oracle)
+    lens5 = lens.copy()
+    lens5[5] = 0
+    lens5[9] = 1
+    check(ctx, oracle, idx, ["-n", "2"], seqs, lens5)
 
 
 def test_rank_bench_layouts_agree(mid_ctx):

@@ -204,3 +204,22 @@ def test_cli_short_reads_match_serial_reference(toy_dir, golden, chunk):
     subprocess.run([bw.HOST_BIN, "align", "-n", "3", "-k", "1", str(toy_dir / "toy.fa"), os.path.join(golden, "short.fq"), str(out)],
                    check=True, env=env, stdout=subprocess.DEVNULL)
     assert open(out, "rb").read() == open(os.path.join(golden, "short_n3k1_t1.aln"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_shard_one_fastq(built, tmp_path):
+    """bench.py --gpus 2 launches its own two ranks (here both on GPU 0, BWB_BENCH_SHARE_DEVICE): the index is replicated, rank r
+    aligns shard r of the logical FASTQ, every rank re-aligns a sample of its neighbour's shard and the checksums must agree."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BWB_BENCH_SHARE_DEVICE="1", BWB_POOL_GB="2", BWB_BENCH_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--genome-mb", "2", "--pool", "24000", "--reads", "6000",
+                        "--steps", "3", "--warmup", "1", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line["shard_sample_parity"] is True and line["config"]["reads_per_gpu_per_step"] == 6000 and line["value"] > 0
+    # asking for more ranks than the launcher started is an error, not a silent one-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--no-extras"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert bad.returncode != 0 and "launcher started" in bad.stderr

@@ -3,7 +3,7 @@
 usage: fuzz_parity.py [n_configs] [seed]"""
 import os, random, subprocess, sys, tempfile
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bwbble_amd as bw
 import oracle_lib

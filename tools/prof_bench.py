@@ -2,7 +2,7 @@
 """Developer tool: one -n <d> batch on the files bench.py left in /tmp/bwb_bench (for rocprofv3 --pmc passes).
 usage: prof_bench.py <n_fwd_chars> <n_reads> <n_diff>"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bwbble_amd as bw
 work = os.environ.get("BWB_BENCH_DIR", "/tmp/bwb_bench")

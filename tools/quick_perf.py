@@ -3,7 +3,7 @@
 usage: quick_perf.py <n_fwd_chars> <n_reads> <n_diff> [check_reads]"""
 import os, subprocess, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bwbble_amd as bw
 
