@@ -68,7 +68,7 @@ void free_bwt(bwt_t *BWT);
 /* index.c */
 int index_bwt(const char *fastaFname, const char *extSAFname);         /* bwt.c:29-63 */
 void fasta2ref(const char *fastaFname, const char *refFname, const char *annFname, unsigned char **seq, bwtint_t *totalSeqLen); /* io.c:190-321 */
-bwt_t *construct_bwt(unsigned char *seq, bwtint_t length);             /* bwt.c:161-218 */
+bwt_t *construct_bwt(unsigned char *seq, bwtint_t length, const char *extSAFname); /* bwt.c:161-218; extSAFname: esa2bwt bwt.c:132-158 */
 fasta_annotations_t *annf2ann(const char *annFname);                   /* io.c:324-349 */
 void free_ann(fasta_annotations_t *a);
 

@@ -367,21 +367,46 @@ static uint64_t *build_sa(const unsigned char *seq, uint64_t n) {
 }
 
 /* bwt.c:161-218 (is_bwt is.c:214-243, pack_word io.c:590-609, compute_C bwt.c:266-277, compute_O bwt.c:280-291) */
-bwt_t *construct_bwt(unsigned char *ref, bwtint_t length) {
+bwt_t *construct_bwt(unsigned char *ref, bwtint_t length, const char *extSAFname) {
 	bwt_t *B = (bwt_t *)calloc(1, sizeof(bwt_t));
 	B->length = length + 1;
 	B->num_sa = (bwtint_t)ceil(((double)B->length) / SA_INTERVAL);
 	B->SA = (bwtint_t *)calloc(B->num_sa, sizeof(bwtint_t));
-	double t = wall();
-	uint64_t *SA = build_sa(ref, length);
-	printf("Suffix sort time: %.2f sec\n", wall() - t);
 	unsigned char *bw = (unsigned char *)malloc(B->length);
-	for (bwtint_t i = 0; i <= length; i++) {
-		if (i % SA_INTERVAL == 0) B->SA[i / SA_INTERVAL] = SA[i];
-		if (SA[i] == 0) { B->sa0_index = i; bw[i] = 0; }
-		else bw[i] = ref[SA[i] - 1];
+	if (!B->SA || !bw) bwb_die("construct_bwt: Could not allocate memory for the compressed SA");
+	if (extSAFname) {
+		/* esa2bwt, bwt.c:132-158: the suffix array comes from an external sorter (eSAIS) as 40-bit little-endian entries for
+		 * rows 1..n (row 0 is the empty suffix); it is streamed, never held in memory */
+		printf("Computing BWT from precomputed eSAIS SA \n");
+		FILE *sf = fopen(extSAFname, "rb");
+		if (!sf) bwb_die("esa2bwt: Cannot open the ext SA file: %s!", extSAFname);
+		B->SA[0] = length;
+		bw[0] = ref[length - 1];
+		int have0 = 0;
+		for (bwtint_t i = 1; i <= length; i++) {
+			bwtint_t v = 0;
+			if (fread(&v, 5, 1, sf) < 1) bwb_die("esa2bwt: Could not read ext SA from file: %s!", extSAFname);
+			if (v >= length) bwb_die("esa2bwt: suffix %llu in %s is outside the text", (unsigned long long)v, extSAFname);
+			if (i % SA_INTERVAL == 0) B->SA[i / SA_INTERVAL] = v;
+			if (v == 0) { B->sa0_index = i; bw[i] = 0; have0 = 1; }
+			else bw[i] = ref[v - 1];
+		}
+		fclose(sf);
+		if (!have0) bwb_die("esa2bwt: %s does not contain suffix 0", extSAFname);
+	} else {
+		double t = wall();
+		uint64_t *SA = build_sa(ref, length);
+		printf("Suffix sort time: %.2f sec\n", wall() - t);
+		FILE *dump = getenv("BWB_DUMP_SA") ? fopen(getenv("BWB_DUMP_SA"), "wb") : NULL; /* test aid: the SA in the external 40-bit format */
+		for (bwtint_t i = 0; i <= length; i++) {
+			if (i % SA_INTERVAL == 0) B->SA[i / SA_INTERVAL] = SA[i];
+			if (SA[i] == 0) { B->sa0_index = i; bw[i] = 0; }
+			else bw[i] = ref[SA[i] - 1];
+			if (dump && i) fwrite(&SA[i], 5, 1, dump);
+		}
+		if (dump) fclose(dump);
+		free(SA);
 	}
-	free(SA);
 	B->num_words = (bwtint_t)ceil(((double)B->length) / 8);
 	B->bwt = (uint32_t *)calloc(B->num_words, sizeof(uint32_t));
 	B->num_occ = (bwtint_t)ceil(((double)B->length) / OCC_INTERVAL);
@@ -400,7 +425,6 @@ bwt_t *construct_bwt(unsigned char *ref, bwtint_t length) {
 
 int index_bwt(const char *fastaFname, const char *extSAFname) { /* bwt.c:29-63 */
 	printf("**** BWT Index **** \n");
-	if (extSAFname) bwb_die("index: external eSAIS suffix arrays (-e) are not supported by this build");
 	size_t L = strlen(fastaFname) + 8;
 	char *annFname = (char *)malloc(L), *bwtFname = (char *)malloc(L), *refFname = (char *)malloc(L);
 	snprintf(annFname, L, "%s.ann", fastaFname);
@@ -408,9 +432,21 @@ int index_bwt(const char *fastaFname, const char *extSAFname) { /* bwt.c:29-63 *
 	snprintf(refFname, L, "%s.ref", fastaFname);
 	unsigned char *seq;
 	bwtint_t seqLen;
-	fasta2ref(fastaFname, refFname, annFname, &seq, &seqLen);
+	if (!extSAFname) fasta2ref(fastaFname, refFname, annFname, &seq, &seqLen);
+	else { /* ref2seq, io.c:158-185: the text comes from the .ref file that an earlier fasta2ref wrote (the external sorter worked on it) */
+		FILE *rf = fopen(refFname, "rb");
+		if (!rf) bwb_die("ref2seq: Cannot open .ref file: %s!", refFname);
+		fseek(rf, 0, SEEK_END);
+		long sz = ftell(rf);
+		fseek(rf, 0, SEEK_SET);
+		seq = (unsigned char *)malloc((size_t)sz + 16);
+		if (!seq || fread(seq, 1, (size_t)sz, rf) != (size_t)sz) bwb_die("ref2seq: Could not read the .ref file: %s!", refFname);
+		fclose(rf);
+		seqLen = (bwtint_t)sz;
+		printf("Done reading FASTA file. Total sequence length read = %llu\n", (unsigned long long)seqLen);
+	}
 	double t = wall();
-	bwt_t *B = construct_bwt(seq, seqLen);
+	bwt_t *B = construct_bwt(seq, seqLen, extSAFname);
 	printf("Total BWT construction time: %.2f sec\n", wall() - t);
 	free(seq);
 	store_bwt(B, bwtFname);
