@@ -242,18 +242,19 @@ def end_to_end(ctx, p, batch, nb, B, value):
     """The same batches with everything a caller pays: host -> pinned staging -> HBM, kernels, hit log -> host, in read order.
     Uploads and result copies ride their own streams next to the kernels (the product's `align` loop, host/align_gpu.c)."""
     ctx.flush()
+    ne = 2 * nb if nb >= 3 else nb  # two passes over the pool: every slot is uploaded, run and fetched twice
     t0 = time.perf_counter()
-    for j in range(nb):
-        ctx.slot_upload(j, p, *batch(j))
-        ctx.slot_submit(j)
+    for j in range(ne):
+        ctx.slot_upload(j % nb, p, *batch(j % nb))
+        ctx.slot_submit(j % nb)
         if j >= 2:
-            ctx.slot_result(j - 2)
-    for j in range(max(0, nb - 2), nb):
-        ctx.slot_result(j)
+            ctx.slot_result((j - 2) % nb)
+    for j in range(max(0, ne - 2), ne):
+        ctx.slot_result(j % nb)
     ctx.flush()
     dt = time.perf_counter() - t0
-    v = nb * B / dt
-    return {"value": round(v, 1), "unit": "reads/s", "batches": nb, "of_value": round(v / value, 4),
+    v = ne * B / dt
+    return {"value": round(v, 1), "unit": "reads/s", "batches": ne, "of_value": round(v / value, 4),
             "includes": "H2D of reads (pinned staging), kl_calc_d + kl_search, D2H of the hit log, reordering into read order"}
 
 

@@ -78,6 +78,11 @@ template <typename P> struct LaneReq {
  * way against 10.9 G/s (1.4 TB/s) when every lane loads its own bucket with 8 x dwordx4 - at GRCh37 scale the per-lane shape is
  * bound by address translation, 64 different pages per instruction, not by HBM.  Called by EVERY lane of the wave
  * (blk == NONE32: this lane wants nothing; it still loads for the others). */
+/* cache policy of the bucket loads (aux operand: 1 = sc0, 2 = nt, 16 = sc1).  A non-temporal policy, meant to keep the per-lane
+ * metadata in L2, measured 2 % slower at 884 M rows (tools/r2_probe5.sh): left at the default. */
+#ifndef BWB_GATHER_AUX
+#define BWB_GATHER_AUX 0
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
 
 /* Both sides of an SA interval for every lane of the wave.  `need`: this lane wants a rank at pL and pU.  When L-1 and U fall
@@ -108,17 +113,19 @@ __device__ __forceinline__ uint32_t wave_fetch_pair(const uint4 *__restrict__ bu
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
-		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oL[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 64 * r), 16, 0, 0);
-		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oU[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 512 + 64 * r), 16, 0, 0);
+		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oL[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 64 * r), 16, 0, BWB_GATHER_AUX);
+		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oU[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 512 + 64 * r), 16, 0, BWB_GATHER_AUX);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the slices have landed in LDS */
 	__builtin_amdgcn_wave_barrier();
 	const int rot = lane >> 1;
-	const Lds<u32x4> mineL = stage + lane * 8, mineU = mineL + 512;
+	/* (a lane that wants nothing, or whose position is one of the two special ones, reads whatever its row holds: the values
+	 * are only used under `regular`; a same-bucket pair reads the one row twice instead of copying 32 registers) */
+	const Lds<u32x4> mineL = stage + lane * 8, mineU = mineL + (wantU ? 512 : 0);
 #pragma unroll
-	for (int k = 0; k < 8; k++) { u32x4 v = (u32x4)(0u); if (wantL) v = mineL[(k + rot) & 7]; ra.d[k] = make_uint4(v.x, v.y, v.z, v.w); }
+	for (int k = 0; k < 8; k++) { const u32x4 v = mineL[(k + rot) & 7]; ra.d[k] = make_uint4(v.x, v.y, v.z, v.w); }
 #pragma unroll
-	for (int k = 0; k < 8; k++) { uint4 w = ra.d[k]; if (wantU) { const u32x4 v = mineU[(k + rot) & 7]; w = make_uint4(v.x, v.y, v.z, v.w); } rb.d[k] = w; }
+	for (int k = 0; k < 8; k++) { const u32x4 v = mineU[(k + rot) & 7]; rb.d[k] = make_uint4(v.x, v.y, v.z, v.w); }
 	__builtin_amdgcn_s_waitcnt(0xc07f); /* the buckets are in registers before the children overwrite the staging area */
 	return (wantL ? 1u : 0u) + (wantU ? 1u : 0u);
 }
@@ -552,7 +559,9 @@ template <typename P, bool WIDE> struct LHeap {
 			top_valid = false;
 		} else {
 			cst--;
-			top_valid = false; /* the new top is fetched at the end of the iteration, unless a match pushed by then has taken its place */
+			top_valid = false; /* the new top is fetched at the end of the iteration, unless a match pushed by then has taken its place
+			                      (fetching it here, together with the rank buckets, measured 2 % slower at GRCh37 scale: the sector is
+			                      wasted whenever a match is pushed; tools/r2_probe6.sh) */
 		}
 		num_entries--;
 	}

@@ -48,7 +48,9 @@ def mid_ctx(mid, oracle):
 @pytest.mark.parametrize("flags", [["-n", "0"], ["-n", "2"], ["-n", "3"], ["-n", "4", "-o", "2", "-e", "4"],
                                    ["-n", "3", "-l", "0"], ["-n", "3", "-k", "0", "-l", "40"],
                                    ["-S", "-n", "0"], ["-S", "-n", "3"], ["-S", "-n", "4", "-o", "2", "-e", "4"],
-                                   ["-P", "-n", "0"], ["-P", "-n", "3"], ["-P", "-S", "-n", "2"]])
+                                   ["-P", "-n", "0"], ["-P", "-n", "3"], ["-P", "-S", "-n", "2"],
+                                   # penalties beyond the 12-score LDS window of bucket states: the global row is used as well
+                                   ["-n", "3", "-O", "20", "-E", "13", "-e", "2"], ["-n", "4", "-M", "14", "-O", "15", "-E", "2", "-o", "2", "-e", "3"]])
 def test_mid_genome_matches_oracle(mid_ctx, oracle, flags):
     d, fa, ctx, idx = mid_ctx
     seqs, lens = synth_reads(fa, str(d / "a.fq"), 3000, 100, 5, sub=1.5, indel=2.0, npct=2.0)
@@ -115,6 +117,7 @@ def test_parked_and_resumed_reads_are_exact(mid, oracle, monkeypatch, env):
     check(ctx, oracle, idx, ["-n", "4", "-o", "2", "-e", "3"], seqs[:1500], lens[:1500])
     check(ctx, oracle, idx, ["-P", "-n", "2"], seqs, lens)
     check(ctx, oracle, idx, ["-S", "-n", "2"], seqs, lens)
+    check(ctx, oracle, idx, ["-n", "3", "-O", "20", "-E", "13", "-e", "2"], seqs[:1500], lens[:1500])
     ctx.close()
 
 
