@@ -284,7 +284,7 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t per_lane = ((size_t)c->keep << 10) + std::min<size_t>((size_t)1536 << 10, index_mb << 9);
 	size_t want = std::max<size_t>((size_t)1 << 30, lanes * per_lane / 4 * 5 * (c->wide ? 2 : 1));
 	if (want > ceiling) want = ceiling;
-	if (getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
+	if (getenv("BWB_POOL_GB") && *getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
 	if (want < ((size_t)64 << 20)) want = (size_t)64 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path) */
 	want &= ~(size_t)(POOL_REGIONS * 4096 - 1);
 	if (c->d_pool.p && c->d_pool.bytes >= want) return BWB_OK;
@@ -302,7 +302,7 @@ static int ensure_pool2(bwb_hip_ctx *c) {
 	size_t fr = 0, tot = 0;
 	HIPCHK(hipMemGetInfo(&fr, &tot));
 	size_t want = std::min<size_t>((size_t)8 << 30, fr / 4);
-	if (getenv("BWB_POOL_GB")) want = std::max<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, (size_t)256 << 20);
+	if (getenv("BWB_POOL_GB") && *getenv("BWB_POOL_GB")) want = std::max<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, (size_t)256 << 20);
 	want = std::max<size_t>(want, (size_t)64 << 20) & ~(size_t)(POOL_REGIONS * 4096 - 1);
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the chunk pool of the re-run classes");
 	HIPCHK(c->d_pool2.alloc(want));
@@ -852,7 +852,7 @@ static int read_device_stats(bwb_hip_ctx *c) {
 		        st[STAT_N], st[STAT_N_MAX], st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS] ? (double)st[STAT_N] / (double)st[STAT_WAVE_ITERS] : 0.0, st[STAT_PARKED]);
 		if (st[STAT_STAMPS + 3]) {
 			double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[STAT_STAMPS + k];
-			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E(exact)", "-", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "-", "-" };
+			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E(exact)", "-", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "C.gather(exchange,loads,wait)", "-" };
 			fprintf(stderr, "[bwb] stamps (%% of lane cycles):");
 			for (int k = 0; k < 16; k++) if (st[STAT_STAMPS + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[STAT_STAMPS + k] / tot);
 			fprintf(stderr, "\n");

@@ -852,6 +852,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		if (nreq > COOP_MAX_REQ) {
 			LaneReq<P> ra, rb;
 			n_bkt += wave_fetch_pair<P>(buckets, last_row, need_rank, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
+			STAMP(14);
 			if (need_rank) ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
 		} else if (nreq > 0) {
 			unsigned long long rm = rmask;

@@ -27,7 +27,7 @@ for f in glob.glob(src + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         launches[short(r["Kernel_Name"])].append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 3))
 line = None
-for name in ("r2_bench_line.json", "r2_bench_line_under_rocprof.json"):
+for name in ("r2_bench_line.json", "r2_bench_line_driver_args.json", "r2_bench_line_under_rocprof.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, name))
