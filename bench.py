@@ -187,7 +187,7 @@ def main():
         dev = bkt * DEV_BYTES_PER_BUCKET + extra_dev
         return {"launches": int(launches), "ms_per_launch": round(ms / max(launches, 1), 3), "ms_total": round(ms, 3),
                 "visits_per_step": int(vis / a.steps), "algorithmic_GBs": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                "device_bytes_per_step": int(dev / a.steps), "device_GBs": round(dev / (ms * 1e-3) / 1e9, 1) if ms else 0.0,
+                "bucket_bytes_per_step": int(bkt * DEV_BYTES_PER_BUCKET / a.steps), "device_bytes_per_step": int(dev / a.steps), "device_GBs": round(dev / (ms * 1e-3) / 1e9, 1) if ms else 0.0,
                 "device_frac": round(dev / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else 0.0}
     heap_bytes = (st.heap_pops + st.heap_pushes) * (32 if p.max_gapo > 1 else 16) + st.lane_iterations * 8  # heap entries + per-position records
     k_search = kernel(vis_search, st.ms_search, st.launches_search, st.bucket_loads_search, heap_bytes)
@@ -200,7 +200,8 @@ def main():
         if (pj.get("genome_mb"), pj.get("reads"), pj.get("ndiff")) == (a.genome_mb, B, a.ndiff) and dom_name in pj:
             traffic = pj[dom_name]["hbm_bytes_per_step"] * a.steps / max(dom["launches"], 1)
             traffic_src = ("profiles/r2_c3_pmc.json: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), "
-                           "HBM bytes per step there x steps / launches here = bytes per launch; NOT measured in this run")
+                           "HBM bytes per step there x steps / launches here = bytes per launch; NOT measured in this run; an upper bound for kl_search "
+                           "(the x2 is right for its 128-byte bucket requests, not for its 64-byte metadata requests: DESIGN.md section 4)")
     index_mb = bwt.length / 1e6  # one 128-byte bucket per 128 BWT characters
     scale = {3_100_000_000: "C3 GRCh37-scale", 48_000_000: "C2 chr21-scale"}.get(n_fwd, f"{n_fwd / 1e6:.0f} M-char")
     residency = (f"device index {index_mb:.0f} MB: Infinity-Cache (256 MB) resident, so this is the fraction of the HBM peak reached from cache"

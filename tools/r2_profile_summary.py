@@ -64,6 +64,9 @@ if line:
             out[k]["device_bytes_per_step"] = kk["device_bytes_per_step"]
             out[k]["traffic_over_algorithmic"] = round(out[k]["hbm_bytes_per_step"] / alg, 3)
             out[k]["traffic_over_device_bytes"] = round(out[k]["hbm_bytes_per_step"] / kk["device_bytes_per_step"], 3)
+            if "bucket_bytes_per_step" in kk:  # x2 only for the 128-byte bucket requests, the 64-byte metadata requests as counted
+                raw_read = out[k]["hbm_read_bytes_corrected"] / 2 / 2
+                out[k]["hbm_bytes_per_step_buckets_only_doubled"] = raw_read + kk["bucket_bytes_per_step"] / 2 + out[k]["hbm_write_bytes"] / 2
 json.dump(out, open(os.path.join(dst, "r2_c3_pmc.json"), "w"), indent=1)
 json.dump({"per_launch_ms": launches, "source": "rocprofv3 --kernel-trace of bench.py --steps 3 --warmup 1 --no-extras (C3)"},
           open(os.path.join(dst, "r2_c3_kernel_launches.json"), "w"), indent=1)

@@ -11,5 +11,8 @@ for cfg in "-n 3" "-n 4 -o 2 -e 3 -l 20 -k 1" "-S -n 2" "-P -n 2"; do $T/oracle_
 cmp $T/o.aln $G/ragged_p2.aln
 cp $G/toy.fa $T/ && (cd $T && ./bwbble_asan index toy.fa > /dev/null && ./bwbble_asan fasta2ref toy.fa > /dev/null)
 cmp $T/toy.fa.bwt $G/toy.fa.bwt && cmp $T/toy.fa.ann $G/toy.fa.ann
+# the prefix-doubling phase of the suffix sort (long exact repeats) and the external-SA ingest
+python3 -c "import sys; sys.path.insert(0, '$R'); sys.path.insert(0, '$R/tests'); import test_host_tools as t; t._repeat_rich_fasta('$T/rep.fa')"
+(cd $T && BWB_DUMP_SA=$T/rep.sa5 ./bwbble_asan index rep.fa > /dev/null && cp rep.fa.bwt a.bwt && ./bwbble_asan index -e rep.sa5 rep.fa > /dev/null && cmp a.bwt rep.fa.bwt)
 echo "sanitizer run clean"
 rm -rf $T
