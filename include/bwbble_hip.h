@@ -85,7 +85,9 @@ void bwb_default_params(bwb_params *p);                       /* align.c:22-38 *
  * bwt_t arrays (mg-aligner/bwt.h:19-40, file layout bwt.c:66-82):
  *   hdr = {length, num_words, num_sa, num_occ, sa0_index}, C[17], bwt[num_words], O[num_occ*16].
  * The index is re-laid-out on the GPU into 128-byte rank buckets; the host arrays are
- * not referenced after return. */
+ * not referenced after return.  One context per device is the intended use: with the first batch a context sizes its heap
+ * chunk pool from what the device has free (minus a reserve for the re-run classes and further slots), so a second context
+ * on the same device - tests do that - should be given a budget with the environment variable BWB_POOL_GB. */
 int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
                        const uint64_t *O, bwb_hip_ctx **out);
 void bwb_hip_ctx_destroy(bwb_hip_ctx *ctx);
