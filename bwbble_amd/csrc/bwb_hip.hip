@@ -852,7 +852,7 @@ static int read_device_stats(bwb_hip_ctx *c) {
 		        st[STAT_N], st[STAT_N_MAX], st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS] ? (double)st[STAT_N] / (double)st[STAT_WAVE_ITERS] : 0.0, st[STAT_PARKED]);
 		if (st[STAT_STAMPS + 3]) {
 			double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[STAT_STAMPS + k];
-			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E(exact)", "-", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "C.gather(exchange,loads,wait)", "-" };
+			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E.top-reload", "E.exact-step", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "C.gather(exchange,loads,wait)", "E.exact-done/hits" };
 			fprintf(stderr, "[bwb] stamps (%% of lane cycles):");
 			for (int k = 0; k < 16; k++) if (st[STAT_STAMPS + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[STAT_STAMPS + k] / tot);
 			fprintf(stderr, "\n");

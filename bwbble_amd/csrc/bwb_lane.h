@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				nxi_valid = !ovf && !exact_done && s != curT - 1;
 				if (nxi_valid) nxi = (lbase + cursel * lcap)[s];
 			}
+			STAMP(6);
 			if (exact_done && !ovf && seeding) {
 				/* :269-279: one entry per interval, i = readLen - 12, a 12-long all-M path; no interval: no alignment */
 				mode = LMODE_POP; seeding = false; r_stop = 0;
@@ -1090,6 +1091,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			}
 		}
 
+		STAMP(15);
 		if (active && !h.top_valid && h.cst != NONE32) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
 			h.load_entry(h.cst, h.top);
 			h.top_valid = true;

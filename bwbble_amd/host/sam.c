@@ -81,6 +81,8 @@ void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFnam
 	uint64_t *ref_pos = (uint64_t *)calloc(n ? n : 1, 8);
 	for (size_t k = 0; k < nm; k++) ref_pos[which[k]] = pos[k];
 
+	int ann_sorted = 1; /* records as fasta2ref writes them: increasing, disjoint */
+	for (int i = 1; i < ann->num_seq; i++) if (ann->seq_anns[i].start_index <= ann->seq_anns[i - 1].end_index) ann_sorted = 0;
 	unsigned char path[272];
 	char *line = (char *)malloc(70000);
 	for (size_t r = 0; r < n; r++) {
@@ -115,9 +117,16 @@ void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFnam
 		if (rp > (BWT->length - 1) / 2) { strand = 0; aln_pos = ((BWT->length - 1) - rp - 1) - (uint64_t)ref_len + 1; }
 		else { strand = 1; aln_pos = rp; }
 		const int mq = mapq(top1, top2, e[0].num_mm, max_diff);
+		/* the record that contains aln_pos (align.c:796-801 scans linearly; a multi-genome has a record per bubble - 1.3 M at
+		 * GRCh37 scale - and the records are disjoint and in text order, so a binary search finds the same one) */
 		int seqid = -1;
-		for (int i = 0; i < ann->num_seq; i++)
-			if (aln_pos >= ann->seq_anns[i].start_index && aln_pos <= ann->seq_anns[i].end_index) { seqid = i; break; }
+		if (ann_sorted) {
+			int lo = 0, hi = ann->num_seq - 1;
+			while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ann->seq_anns[mid].start_index <= aln_pos) lo = mid; else hi = mid - 1; }
+			if (ann->num_seq > 0 && aln_pos >= ann->seq_anns[lo].start_index && aln_pos <= ann->seq_anns[lo].end_index) seqid = lo;
+		} else
+			for (int i = 0; i < ann->num_seq; i++)
+				if (aln_pos >= ann->seq_anns[i].start_index && aln_pos <= ann->seq_anns[i].end_index) { seqid = i; break; }
 		if (seqid < 0) bwb_die("alns2sam: read %zu maps outside every annotated sequence", r); /* the reference indexes seq_anns[-1] here */
 		fprintf(sam, "%.*s\t%d\t%s\t", (int)reads->name_len[r], name, strand ? SAM_FSR : 0, ann->seq_anns[seqid].name);
 		fprintf(sam, "%d\t%d\t", (int)(aln_pos - ann->seq_anns[seqid].start_index + 1), mq);
