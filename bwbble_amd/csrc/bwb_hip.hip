@@ -253,7 +253,7 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 
 static size_t lane_lds(const bwb_hip_ctx *c) {
 	(void)c;
-	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)(LANE_BLOCK / 64) * (WAVE_LDS_BYTES + 1024); /* base table + per wave: gather staging / children, 1 KB for speculative loads */
+	return (size_t)BWB_BASE_ROWS * 16 * 8 + (size_t)(LANE_BLOCK / 64) * WAVE_LDS_BYTES; /* base table + per wave: gather staging / children */
 }
 
 static uint32_t max_reads_resident(const bwb_hip_ctx *c) {

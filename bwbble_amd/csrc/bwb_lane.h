@@ -130,18 +130,6 @@ __device__ __forceinline__ uint32_t wave_fetch_pair(const uint4 *__restrict__ bu
 	return (wantL ? 1u : 0u) + (wantU ? 1u : 0u);
 }
 
-/* Speculative gather (BWB_SPEC_PREFETCH): bucket `blk` of every lane (NONE32: nothing) is requested into a 1 KB scratch area of
- * the wave that nobody reads - only so that the line sits in L2 / the Infinity Cache when the lane really needs it an
- * iteration later.  Issued after the wait of the real gather, so nothing waits for it before the next iteration does. */
-__device__ __forceinline__ void wave_prefetch(const uint4 *__restrict__ buckets, uint32_t blk, Lds<u32x4> scratch, int lane) {
-	const int sub = lane >> 3, p = lane & 7;
-#pragma unroll
-	for (int r = 0; r < 8; r++) {
-		const uint32_t ob = (uint32_t)__shfl((int)blk, 8 * r + sub);
-		if (ob != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)ob * 8 + p), (void __attribute__((address_space(3))) *)scratch, 16, 0, 0);
-	}
-}
-
 /* pop[j] = #j in the bucket's block at offsets [0, pos & 127], j = 1..15 */
 template <typename P>
 __device__ __forceinline__ void lane_pops(const LaneReq<P> &r, uint32_t pop[16]) {
@@ -459,8 +447,6 @@ template <typename P, bool WIDE> struct LHeap {
 	int num_entries;
 	LEntry<P> top;         /* register mirror of the entry on top of bucket cb's memory stack */
 	bool top_valid;
-	uint32_t sblk;         /* BWB_SPEC_PREFETCH: bucket of the U bound of the entry BELOW the top (the next pop unless this expansion pushes
-	                          a match, which 1 in 4 does), NONE32 when unknown: a hint only */
 
 	/* last word of a 16-byte entry: state|aln_length (10 bits), the one gap run (16), bits 32..34 of L and of U (the
 	 * superblock table covers 2^34 BWT characters, bwb_device.h) */
@@ -470,17 +456,7 @@ template <typename P, bool WIDE> struct LHeap {
 		return w;
 	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { fhead = fnext = NONE32; pused = 0; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; sblk = NONE32; }
-	/* bucket number of the U bound of the entry in slot st (hint for the speculative gather) */
-	__device__ __forceinline__ uint32_t peek_ublk(uint32_t st, P last_row) const {
-		const uint4 *p = chunk_ptr(st >> 6);
-		const uint32_t fill = st & 63u;
-		P U;
-		if (WIDE) { const uint4 w0 = p[fill * 2]; U = (P)(((uint64_t)w0.w << 32) | w0.z); }
-		else { const uint4 w = p[fill]; U = (P)w.y; if (sizeof(P) == 8) U |= (P)((uint64_t)(w.w >> 29) << 32); }
-		U = pos_dec<P>(U);
-		return U >= last_row ? NONE32 : (uint32_t)(U >> 7);
-	}
+	__device__ __forceinline__ void reset() { fhead = fnext = NONE32; pused = 0; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
 	__device__ __forceinline__ void mark(int s) { if (s < 64) neLo |= 1ull << s; else neHi |= 1ull << (s - 64); }
 	__device__ __forceinline__ void unmark(int s) { if (s < 64) neLo &= ~(1ull << s); else neHi &= ~(1ull << (s - 64)); }
 	__device__ __forceinline__ int best(int nb) const {
@@ -490,7 +466,7 @@ template <typename P, bool WIDE> struct LHeap {
 		if (s == cb) return;
 		bstate[cb] = cst;
 		cb = s; cst = bstate[s];
-		top_valid = false; sblk = NONE32;
+		top_valid = false;
 	}
 	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private run of `keep` consecutive
 	 * chunks at the start of its region (a counter: an ordinary read allocates without touching memory); the block's stack
@@ -616,9 +592,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	unsigned char __attribute__((address_space(3))) *wlds = (unsigned char __attribute__((address_space(3))) *)(smem + BWB_BASE_ROWS * 16 * 8) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
 	Lds<u32x4> stage = (Lds<u32x4>)wlds;
 	Lds<P> kids = (Lds<P>)wlds; /* this wave's children; the same LDS as the staging area of the gather, one after the other */
-#ifdef BWB_SPEC_PREFETCH
-	Lds<u32x4> spec_scratch = (Lds<u32x4>)((unsigned char __attribute__((address_space(3))) *)(smem + BWB_BASE_ROWS * 16 * 8) + (LANE_BLOCK / 64) * WAVE_LDS_BYTES + (threadIdx.x >> 6) * 1024);
-#endif
 	__shared__ unsigned long long s_blockfree;
 	__shared__ unsigned int s_active, s_nfree, s_left; /* reads in flight in this block; chunks on its recycle stack; waves that have left */
 	if (threadIdx.x == 0) {
@@ -879,9 +852,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		if (nreq > COOP_MAX_REQ) {
 			LaneReq<P> ra, rb;
 			n_bkt += wave_fetch_pair<P>(buckets, last_row, need_rank, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
-#ifdef BWB_SPEC_PREFETCH
-			wave_prefetch(buckets, (from_pop && need_rank) ? h.sblk : NONE32, spec_scratch, lane);
-#endif
 			STAMP(14);
 			if (need_rank) ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
 		} else if (nreq > 0) {
@@ -1041,7 +1011,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 						}
 						STAMP(13);
 						h.num_entries += nG + nX + n0;
-						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; if (!(top_ok && k0 == 1)) h.sblk = NONE32; }
+						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; }
 						if (k1 > 0) { h.bstate[scX] = st1 + (uint32_t)k1; h.mark(scX); }
 						if (k2 > 0) { h.bstate[scG] = st2 + (uint32_t)k2; h.mark(scG); }
 					}
@@ -1125,9 +1095,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		if (active && !h.top_valid && h.cst != NONE32) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
 			h.load_entry(h.cst, h.top);
 			h.top_valid = true;
-#ifdef BWB_SPEC_PREFETCH
-			h.sblk = (h.cst & 63u) >= 2u ? h.peek_ublk(h.cst - 1u, last_row) : NONE32; /* (the neighbouring 16 bytes: the same sector 3 times in 4) */
-#endif
 		}
 		STAMP(5);
 		if (ovf) finish = true;
