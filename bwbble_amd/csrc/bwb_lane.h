@@ -481,11 +481,7 @@ template <typename P, bool WIDE> struct LHeap {
 			fnext = fhead != NONE32 ? chunk_ptr(fhead)[0].x : NONE32;
 			return c;
 		}
-#ifdef BWB_INTERLEAVE_RUNS /* experiment: chunk k of every lane of the block side by side (the block's hot chunks share pages) */
-		if (pused < keep) return pbase + (pused++) * LANE_BLOCK;
-#else
-		if (pused < keep) return pbase + pused++;
-#endif
+		if (pused < keep) return pbase + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
 		uint32_t c = NONE32;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		while ((uint32_t)old != NONE32) {
@@ -618,11 +614,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 
 	LHeap<P, WIDE> h;
 	const uint32_t region = blockIdx.x % sc.n_regions;
-#ifdef BWB_INTERLEAVE_RUNS
-	h.pbase = (blockIdx.x / sc.n_regions) * LANE_BLOCK * sc.keep + threadIdx.x;
-#else
 	h.pbase = ((blockIdx.x / sc.n_regions) * LANE_BLOCK + threadIdx.x) * sc.keep;
-#endif
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slot * BSTATE_ROW; h.nslots = sc.nslots;
 	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
