@@ -123,7 +123,7 @@ struct bwb_hip_ctx {
 	Slot slots[BWB_MAX_SLOTS];
 	SlotDesc h_descs[BWB_MAX_SLOTS]{};
 	ScratchClass cls[3];
-	DevMem d_pool, d_pool2, d_pool_bump;  /* heap chunk pools (class 0; classes 1-2), POOL_REGIONS equal regions; bump counters (two sets) */
+	DevMem d_pool, d_pool_bump;         /* heap chunk pool, POOL_REGIONS equal regions (the re-run classes use it after a drain); bump counters (two sets) */
 	uint32_t keep = 256;                /* chunks of a lane's private run (BWB_KEEP) */
 	int bpc_search = 2, bpc_calcd = 2;
 	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
@@ -275,7 +275,7 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * 32), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * 32);
 	size_t slot_bytes = 0;
 	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * 32);
-	const size_t reserve = cls1 + cls2 + ((size_t)8 << 30) + 3 * slot_bytes + ((size_t)4 << 30);
+	const size_t reserve = cls1 + cls2 + 3 * slot_bytes + ((size_t)4 << 30);
 	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
 	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
@@ -285,27 +285,13 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	size_t want = std::max<size_t>((size_t)1 << 30, lanes * per_lane / 4 * 5 * (c->wide ? 2 : 1));
 	if (want > ceiling) want = ceiling;
 	if (getenv("BWB_POOL_GB") && *getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
-	if (want < ((size_t)64 << 20)) want = (size_t)64 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path) */
+	if (want < ((size_t)256 << 20)) want = (size_t)256 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path: class 2 must still fit a read) */
 	want &= ~(size_t)(POOL_REGIONS * 4096 - 1);
 	if (c->d_pool.p && c->d_pool.bytes >= want) return BWB_OK;
 	if (c->parked) return BWB_OK; /* parked reads hold chunks of the present pool: keep it (the admission control copes) */
 	c->d_pool.release();
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
 	HIPCHK(c->d_pool.alloc(want));
-	if (!c->d_pool_bump.p) HIPCHK(c->d_pool_bump.alloc(2 * POOL_REGIONS * 64));
-	return BWB_OK;
-}
-
-/* the pool of the re-run classes: separate, because class-0 reads may be parked (holding class-0 chunks) while a re-run runs */
-static int ensure_pool2(bwb_hip_ctx *c) {
-	if (c->d_pool2.p) return BWB_OK;
-	size_t fr = 0, tot = 0;
-	HIPCHK(hipMemGetInfo(&fr, &tot));
-	size_t want = std::min<size_t>((size_t)8 << 30, fr / 4);
-	if (getenv("BWB_POOL_GB") && *getenv("BWB_POOL_GB")) want = std::max<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, (size_t)256 << 20);
-	want = std::max<size_t>(want, (size_t)64 << 20) & ~(size_t)(POOL_REGIONS * 4096 - 1);
-	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the chunk pool of the re-run classes");
-	HIPCHK(c->d_pool2.alloc(want));
 	if (!c->d_pool_bump.p) HIPCHK(c->d_pool_bump.alloc(2 * POOL_REGIONS * 64));
 	return BWB_OK;
 }
@@ -357,7 +343,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.keep = c->keep;
 	s.blocks = blocks;
 	s.ready = true;
-	return k == 0 ? ensure_pool(c) : ensure_pool2(c); /* (after the scratch: the class-0 pool takes what is left over) */
+	return ensure_pool(c); /* (after the scratch: the pool takes what is left over; the re-run classes use it too, after a drain) */
 }
 
 static hipEvent_t get_event(bwb_hip_ctx *c) {
@@ -553,10 +539,12 @@ static int launch_inherit(bwb_hip_ctx *c, int si) {
 }
 
 /* one launch of kl_search in class k: new reads come from `wl`/`n_work` of slot si (n_work 0: only parked reads progress) */
-static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint32_t n_work, uint32_t *counter, bool suspend, bool reset_counter = true) {
+static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint32_t n_work, uint32_t *counter, bool suspend, bool reset_counter = true,
+                         bool force_drain = false) {
 	ScratchClass &s = c->cls[k];
 	const bool resume = k == 0 && c->parked;
-	const uint32_t slice_iters = k == 0 ? c->slice_iters : 0;
+	if (k != 0 && c->parked) return fail(BWB_E_STATE, "a re-run class was launched while reads are parked");
+	const uint32_t slice_iters = (k == 0 && !force_drain) ? c->slice_iters : 0; /* (force_drain: also the time-sliced test mode runs to the end) */
 	Work wk{ wl, n_work, counter, (uint32_t)si, suspend ? 1u : 0u, slice_iters, resume ? 1u : 0u };
 	const size_t lds = lane_lds(c);
 	unsigned int *bump = c->d_pool_bump.as<unsigned int>() + (k == 0 ? 0 : POOL_REGIONS * 16);
@@ -565,7 +553,7 @@ static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 	/* class 0 always runs its full grid: every lane's save word is rewritten by every launch, and the pool geometry
 	 * (regions, private runs) must not change while reads are parked */
 	const uint32_t grid = k == 0 ? (uint32_t)(c->num_cu * c->bpc_search) : std::max<uint32_t>(1, std::min<uint32_t>(s.blocks, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
-	DevMem &pool = k == 0 ? c->d_pool : c->d_pool2;
+	DevMem &pool = c->d_pool;
 	s.sc.pool = pool.as<uint4>(); s.sc.pool_bump = bump;
 	/* one region per 8 blocks up to POOL_REGIONS, so that the few blocks of a small launch (class 2) are not confined to
 	 * a fraction of the pool; a state word names 2^26 chunks of its region */
@@ -682,6 +670,14 @@ static int grow_log(bwb_hip_ctx *c, int si) {
 static int rerun_overflows(bwb_hip_ctx *c, int si) {
 	Slot &s = c->slots[si];
 	std::vector<uint32_t> todo, dids, list;
+	/* The re-run classes take the whole chunk pool (a read that found it empty among 131 072 others gets, in class 1, four times
+	 * its share and in class 2 a five-hundredth of the pool to itself).  So whatever is parked must finish first: one draining
+	 * launch (fed from this slot's exhausted cursor) completes the parked reads of every slot. */
+	if (c->parked) {
+		int rc = launch_search(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), false, false, true);
+		if (rc) return rc;
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
 	/* (n_tot: a carried read that rides along for its D_seed can overflow calculate_d too; it is never searched) */
 	auto load_status = [&]() { s.h_status.resize(s.n_tot); return fetch(c, s.h_status.data(), s.d_status.p, s.n_tot); };
 	auto put_worklist = [&](const std::vector<uint32_t> &v) -> int {

@@ -91,7 +91,7 @@ def test_ragged_batch_with_n_rich_reads(mid_ctx, oracle):
 def test_scratch_overflow_classes_are_exact(mid, oracle, monkeypatch):
     """A tiny heap pool forces reads through the class-1/2 re-run path (still on the GPU): results must not change."""
     d, fa = mid
-    monkeypatch.setenv("BWB_POOL_GB", "0")  # clamps to the 64 MB floor: 65 536 chunks, not enough for 5 000 reads at once
+    monkeypatch.setenv("BWB_POOL_GB", "0")  # clamps to the 256 MB floor: 262 144 chunks, not enough for 5 000 reads at once
     ctx = bw.Context(fa + ".bwt")
     idx = oracle.load_index(fa + ".bwt")
     seqs, lens = synth_reads(fa, str(d / "o.fq"), 5000, 100, 8, sub=2.5)
