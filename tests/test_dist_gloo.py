@@ -47,3 +47,12 @@ def test_shard_bounds_cover_everything():
             b = [dist.shard_bounds(n, world, r) for r in range(world)]
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+
+
+def test_bench_refuses_a_rank_count_it_was_not_launched_with():
+    """`bench.py --gpus N` inside a launcher that started a different number of ranks is an error, before anything touches a GPU
+    (round 1 measured one GPU and printed n_gpus: 1 whatever --gpus said)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--no-extras"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "launcher started 1 rank" in r.stderr
