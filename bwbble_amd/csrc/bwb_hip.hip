@@ -11,7 +11,7 @@
  *                   runs next to the bulk of batch k+1 instead of on a nearly empty GPU.
  *   slot_wait(s)    until every read of the slot is done (normally when the following slice ends; a draining launch
  *                   otherwise), then the rare reads that did not fit the class-0 per-read scratch are re-run - still on the
- *                   GPU - in class 1, then class 2 (fewer lanes, larger lists, their own chunk pool)
+ *                   GPU - in class 1, then class 2 (fewer lanes, larger lists, the whole chunk pool after a draining launch)
  *   slot_result(s)  hit log -> host on the result stream, put into read order
  *
  * batch_upload / batch_run / batch_result are the same on slot 0 with a draining slice (one batch, nothing to overlap).
