@@ -594,12 +594,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	Lds<P> kids = (Lds<P>)wlds; /* this wave's children; the same LDS as the staging area of the gather, one after the other */
 	__shared__ unsigned long long s_blockfree;
 	__shared__ unsigned int s_active, s_nfree, s_left; /* reads in flight in this block; chunks on its recycle stack; waves that have left */
+	__shared__ unsigned int s_need_sum, s_need_cnt;    /* chunks (in units of 16) the reads finished by this block took, and how many reads: admission */
 	if (threadIdx.x == 0) {
 		const uint32_t *bs = sc.blocksave + (size_t)blockIdx.x * 4;
 		const bool keep = wk.resume != 0;
 		s_blockfree = keep ? ~(((unsigned long long)bs[1] << 32) | bs[0]) : ~0ull;
 		s_nfree = keep ? bs[2] : 0u;
-		s_active = 0; s_left = 0;
+		s_active = 0; s_left = 0; s_need_sum = 0; s_need_cnt = 0;
 	}
 	load_base<P>(s_base, ix);
 	Lds<P> kidL = kids + lane, kidU = kids + KID_ROWS * KID_STRIDE + lane;
@@ -687,7 +688,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				const uint32_t blocks_in_region = (gridDim.x + sc.n_regions - 1) / sc.n_regions;
 				const uint32_t avail = s_nfree + left / blocks_in_region;
 				const uint32_t mine = __popcll(__ballot(true) & ((1ull << (threadIdx.x & 63u)) - 1ull));
-				admit = avail >= ADMIT_CHUNKS * (mine + 1) || s_active + mine < 4;
+				/* what a read is expected to take: four times the mean of the reads this block has finished (the needs are heavy-tailed;
+				 * 150 bp reads with -n 5 average 1 750 chunks at GRCh37 scale, 100 bp reads with -n 3 a third of that), at least 1 MB */
+				const uint32_t cnt = s_need_cnt, per = cnt ? (uint32_t)(((unsigned long long)s_need_sum * 64ull) / cnt) : 0u;
+				const uint32_t want = per > ADMIT_CHUNKS ? per : ADMIT_CHUNKS;
+				admit = avail / want >= mine + 1 || s_active + mine < 4;
 			}
 		}
 		bool park = false;
@@ -1115,6 +1120,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			if (!ovf && !outovf) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
 			atomicAdd(d.done, 1u);
 			/* leave every bucket state empty for the next read and give its chunks back */
+			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_sum, (h.pused + h.xcnt + 15u) >> 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			h.release_excess();
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			h.bstate[h.cb] = NONE32;
