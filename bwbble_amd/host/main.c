@@ -84,6 +84,28 @@ int main(int argc, char *argv[]) {
 			}
 		}
 		alns2sam(argv[optind + 1], argv[optind + 2], argv[optind + 3], argv[optind + 4], is_multiref, max_diff, n_gpus);
+	} else if (strcmp(argv[1], "dumpreads") == 0) {
+		/* developer command (CPU only, used by the tests): what fastq2reads made of a FASTQ - per read "name<TAB>codes<TAB>quality" */
+		if (argc < 4) { printf("Usage: bwbble dumpreads <reads_fastq> <out_tsv> \n"); exit(1); }
+		reads_t *reads = fastq2reads(argv[2]);
+		FILE *f = fopen(argv[3], "w");
+		if (!f) { perror(argv[3]); return 1; }
+		for (unsigned r = 0; r < reads->count; r++) {
+			fprintf(f, "%.*s\t", (int)reads->name_len[r], reads->raw + reads->name_off[r]);
+			for (int i = 0; i < reads->len[r]; i++) fputc('0' + reads->seq[(size_t)r * reads->stride + i], f);
+			fprintf(f, "\t%.*s\n", (int)reads->len[r], reads->raw + reads->qual_off[r]);
+		}
+		fclose(f);
+		free_reads(reads);
+	} else if (strcmp(argv[1], "alncat") == 0) {
+		/* developer command (CPU only, used by the tests): .aln -> memory (alnsf2alns_bin) -> .aln (alns2alnf_bin) */
+		if (argc < 4) { printf("Usage: bwbble alncat <in_aln> <out_aln> \n"); exit(1); }
+		alns_batch_t *b = alnsf2alns_bin(argv[2]);
+		FILE *f = fopen(argv[3], "wb");
+		if (!f) { perror(argv[3]); return 1; }
+		for (size_t r = 0; r < b->n_reads; r++) alns2alnf_bin(b->alns + b->aln_off[r], b->aln_off[r + 1] - b->aln_off[r], f);
+		fclose(f);
+		free_alns_batch(b);
 	} else {
 		printf("Error: Unknown command '%s'\n", argv[1]);
 		usage();

@@ -243,3 +243,64 @@ def test_index_from_external_suffix_array(built, golden, tmp_path):
     #  built-in path two lines up)
     bad = subprocess.run([bw.HOST_BIN, "index", "-e", str(tmp_path / "missing.sa5"), str(fa)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert bad.returncode != 0 and "Cannot open the ext SA file" in bad.stdout
+
+
+def _fastq2reads_model(path):
+    """fastq2reads (mg-aligner/io.c:410-515) restated record by record: skip to '@', name = rest of the line (256 chars at most),
+    sequence line -> codes (A0 G1 C2 T3, anything else 4), skip to '+', skip its line, quality line."""
+    data = open(path, "rb").read().decode("latin-1")
+    code = {"A": "0", "a": "0", "G": "1", "g": "1", "C": "2", "c": "2", "T": "3", "t": "3"}
+    out, p, n = [], 0, len(data)
+    while True:
+        p = data.find("@", p)
+        if p < 0:
+            break
+        e = data.find("\n", p)
+        name = data[p + 1:e][:256]
+        s0 = e + 1
+        e = data.find("\n", s0)
+        seq = data[s0:e]
+        p = data.find("+", e)
+        e = data.find("\n", p)
+        q0 = e + 1
+        e = data.find("\n", q0)
+        if e < 0:
+            e = n
+        out.append((name, "".join(code.get(ch, "4") for ch in seq), data[q0:e]))
+        p = e
+    return out
+
+
+@pytest.mark.parametrize("fq", ["wgsim100.fq", "ragged.fq", "short.fq"])
+def test_fastq_reader_on_cpu(built, golden, tmp_path, fq):
+    """host/reads.c without a GPU: names (wgsim style, blanks), codes (lower case, N), qualities, '+name' lines, blank lines and
+    a missing final newline, against a record-by-record restatement of the reference's reader."""
+    out = tmp_path / "reads.tsv"
+    run([bw.HOST_BIN, "dumpreads", os.path.join(golden, fq), str(out)])
+    got = [tuple(ln.split("\t")) for ln in open(out).read().split("\n")[:-1]]
+    assert got == _fastq2reads_model(os.path.join(golden, fq))
+    # the Python-side loader used by the GPU tests sees the same codes on the plain 4-line files
+    if fq != "wgsim100.fq":
+        seqs, lens = bw.load_fastq_codes(os.path.join(golden, fq))
+        assert ["".join(map(str, seqs[i, :lens[i]])) for i in range(len(lens))] == [g[1] for g in got]
+
+
+@pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln"])
+def test_aln_reader_and_writer_round_trip(built, golden, tmp_path, aln):
+    """host/aln_io.c without a GPU.  The reference's loader fills aln_path in pair order (align.c:466-476), i.e. it holds the
+    align-time path reversed - eval_aln and the CIGAR code work on that orientation (align.c:588-609) and so does ours.  So
+    .aln -> alnsf2alns_bin -> alns2alnf_bin reverses the run-length pairs of a gapped record and leaves everything else alone,
+    and doing it twice is the identity."""
+    once, twice = tmp_path / "1.aln", tmp_path / "2.aln"
+    run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(once)])
+    run([bw.HOST_BIN, "alncat", str(once), str(twice)])
+    src = open(os.path.join(golden, aln), "rb").read()
+    assert open(twice, "rb").read() == src
+    import oracle_lib
+    a, b = oracle_lib.parse_aln(src), oracle_lib.parse_aln(open(once, "rb").read())
+    assert len(a) == len(b)
+    for ra, rb in zip(a, b):
+        assert len(ra) == len(rb)
+        for ea, eb in zip(ra, rb):
+            assert {k: v for k, v in ea.items() if k != "states"} == {k: v for k, v in eb.items() if k != "states"}
+            assert ea["states"] == eb["states"][::-1]
