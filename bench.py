@@ -267,7 +267,10 @@ def rank_micro(ctx, index_mb):
         ms, _ = ctx.rank_bench(n, iters=3, seed=7, lane=lane)
         res[name] = {"ms": round(ms, 3), "Gvisits_per_s": round(n / ms / 1e6, 2), "device_GBs": round(n * DEV_BYTES_PER_BUCKET / ms / 1e6, 1),
                      "device_frac": round(n * DEV_BYTES_PER_BUCKET / ms / 1e6 / HBM_PEAK_GBS, 4),
-                     "algorithmic_GBs": round(n * ALG_BYTES_PER_VISIT / ms / 1e6, 1), "algorithmic_frac": round(n * ALG_BYTES_PER_VISIT / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                     "algorithmic_GBs": round(n * ALG_BYTES_PER_VISIT / ms / 1e6, 1)}
+    res["note"] = ("device_frac = 128-byte buckets actually fetched / launch time / HBM peak: the roofline fraction of this kernel. "
+                   "algorithmic_GBs prices the same visits at the reference layout's 192 B (SURVEY 8d) for comparison with `roofline.achieved`; "
+                   "it is 1.5 x device_GBs by construction and not a fraction of anything")
     return res
 
 
