@@ -49,7 +49,9 @@ struct DevMem {
 	~DevMem() { release(); }
 	void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 	hipError_t alloc(size_t n) { release(); hipError_t e = hipMalloc(&p, n ? n : 1); if (e == hipSuccess) bytes = n; else p = nullptr; return e; }
-	hipError_t reserve(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(n); } /* contents are NOT kept */
+	/* contents are NOT kept; grows by half again at least, so that a stream of slightly larger batches does not reallocate (hipFree
+	 * synchronises the whole device and would stall the queued slices) */
+	hipError_t reserve(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(p ? std::max(n, bytes + bytes / 2) : n); }
 	template <typename T> T *as() const { return (T *)p; }
 };
 struct PinMem {
@@ -129,7 +131,8 @@ struct bwb_hip_ctx {
 	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
 	bool parked = false;                /* reads may be parked in the class-0 save area (the last class-0 launch was a non-draining slice) */
 	uint64_t n_launches = 0;            /* class-0 search launches so far */
-	std::vector<hipEvent_t> launch_ev;  /* launch_ev[k-1]: recorded after class-0 search launch k */
+	std::vector<hipEvent_t> launch_ev;  /* launch_ev[k-1-ev_base]: recorded after class-0 search launch k */
+	uint64_t ev_base = 0;               /* launches whose events have been recycled (no slot in flight can wait for them) */
 	std::vector<PendingTime> pending;
 	std::vector<hipEvent_t> free_events;
 	uint32_t slice_iters = 0;           /* BWB_SLICE_ITERS: test knob, time-sliced launches */
@@ -408,6 +411,7 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	HIPCHK(hipSetDevice(c->device));
 	Slot &s = c->slots[si];
 	if (s.submitted && !s.complete) { rc = slot_wait(c, si); if (rc) return rc; } /* the slot is being reused */
+	if (s.uploaded) HIPCHK(hipEventSynchronize(s.ev_up.e)); /* its previous H2D copy has left the pinned staging buffers */
 	/* every slot in flight runs under the same parameters (they are launch arguments) */
 	if (c->have_params && memcmp(&c->p, p, sizeof(*p)) != 0 && (any_in_flight(c) || c->parked)) { rc = bwb_hip_flush(c); if (rc) return rc; }
 	const bool wide = p->max_gapo > 1;
@@ -583,6 +587,12 @@ static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 		HIPCHK(hipEventRecord(le, c->stream));
 		c->launch_ev.push_back(le);
 		c->n_launches++;
+		/* slot_wait starts at the slot's own launch: events of launches before the oldest slot in flight are never needed again */
+		uint64_t oldest = c->n_launches;
+		for (const Slot &t : c->slots) if (t.submitted && !t.complete && t.launch) oldest = std::min(oldest, t.launch);
+		size_t drop = 0;
+		while (c->ev_base + drop + 1 < oldest && drop < c->launch_ev.size()) c->free_events.push_back(c->launch_ev[drop++]);
+		if (drop) { c->launch_ev.erase(c->launch_ev.begin(), c->launch_ev.begin() + (long)drop); c->ev_base += drop; }
 	}
 	if (c->dbg) {
 		HIPCHK(hipStreamSynchronize(c->stream));
@@ -608,7 +618,7 @@ static int submit(bwb_hip_ctx *c, int si, bool suspend) {
 	if (rc) return rc;
 	HIPCHK(hipStreamWaitEvent(c->stream, s.ev_up.e, 0));
 	HIPCHK(hipMemsetAsync(s.d_ctl.p, 0, 256, c->stream));
-	s.submitted = true; s.complete = false; s.fetched = false;
+	s.submitted = true; s.complete = false; s.fetched = false; s.launch = 0;
 	if (s.n_reads == 0) { s.complete = true; s.launch = c->n_launches; return BWB_OK; }
 	HIPCHK(hipMemsetAsync(s.d_n.p, 0, (size_t)s.n_reads * 4, c->stream));
 	HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_tot, c->stream));
@@ -694,7 +704,7 @@ static int rerun_overflows(bwb_hip_ctx *c, int si) {
 			if (s.h_status[i] == ST_D_OVF) dids.push_back(i);
 		}
 		if (todo.empty()) return BWB_OK;
-		c->stats.n_overflow_reads += todo.size();
+		if (k == 1) c->stats.n_overflow_reads += todo.size(); /* (class 2 re-runs a subset of these) */
 		rc = ensure_class(c, k);
 		if (rc) return rc;
 		if (!dids.empty()) { /* calculate_d first: it leaves ST_OK, or ST_D_OVF again (then the next class tries) */
@@ -744,7 +754,7 @@ static int slot_wait(bwb_hip_ctx *c, int si) {
 	 * queued any more, launch a draining slice. */
 	uint64_t L = s.launch;
 	for (;;) {
-		HIPCHK(hipEventSynchronize(c->launch_ev[L - 1]));
+		HIPCHK(hipEventSynchronize(c->launch_ev[L - 1 - c->ev_base]));
 		unsigned int done = 0;
 		int rc = fetch(c, &done, s.ctl_done(), 4);
 		if (rc) return rc;
@@ -843,16 +853,29 @@ static int read_device_stats(bwb_hip_ctx *c) {
 	c->stats.bucket_loads_search = st[STAT_BKT_SEARCH]; c->stats.bucket_loads_calc_d = st[STAT_BKT_CALCD];
 	c->stats.n_parked_reads = st[STAT_PARKED];
 	c->stats.lane_iterations = st[STAT_N]; c->stats.wave_iterations = st[STAT_WAVE_ITERS];
+#ifdef BWB_HIST
+	{
+		static const char *hn[H_N] = { "iter", "pop", "pop_from_mirror", "pop_gapped", "pruned", "hit", "exact_start", "expand", "exact_step", "need_rank", "same_bkt", "two_bkt",
+			"w1", "w2", "w3_4", "w5_8", "w9_32", "w33_128", "w_big", "ne0", "ne1", "ne2", "ne3_4", "ne5_8", "ne9+", "push_gap", "push_mis", "push_match",
+			"del_ok", "mm_ok", "ins_ok", "top_reload", "wave_iters", "wave_gaploop_trips", "wave_misloop_trips", "wave_matchloop_trips", "wave_any_two_bkt", "wave_any_wide8",
+			"wave_nreq_le16", "alpha", "exact_multi", "finish", "alloc", "wave_any_exact", "wave_any_expand", "wave_all_exact", "exp_same_w1", "exp_same_w2_4" };
+		fprintf(stderr, "[bwb hist]");
+		for (int k = 0; k < H_N; k++) fprintf(stderr, " %s=%llu", hn[k], st[STAT_HIST + k]);
+		fprintf(stderr, "\n");
+	}
+#endif
+#ifdef BWB_STAMPS
+	if (st[STAT_STAMPS + 3]) {
+		double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[STAT_STAMPS + k];
+		const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E.top-reload", "E.exact-step", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "C.gather(exchange,loads,wait)", "E.exact-done/hits" };
+		fprintf(stderr, "[bwb] stamps (%% of lane cycles):");
+		for (int k = 0; k < 16; k++) if (st[STAT_STAMPS + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[STAT_STAMPS + k] / tot);
+		fprintf(stderr, "\n");
+	}
+#endif
 	if (c->dbg) {
 		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu, wave iterations %llu (%.1f of 64 lanes busy), reads parked at slice ends %llu\n",
 		        st[STAT_N], st[STAT_N_MAX], st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS] ? (double)st[STAT_N] / (double)st[STAT_WAVE_ITERS] : 0.0, st[STAT_PARKED]);
-		if (st[STAT_STAMPS + 3]) {
-			double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[STAT_STAMPS + k];
-			const char *nm[16] = { "top", "A(pop)", "B(issue)", "C(rank)", "D.tail", "E.top-reload", "E.exact-step", "F(finish,grab)", "D.prune/hit", "D.masks", "D.reserve", "D.templates", "D.gap", "D.mm/match", "C.gather(exchange,loads,wait)", "E.exact-done/hits" };
-			fprintf(stderr, "[bwb] stamps (%% of lane cycles):");
-			for (int k = 0; k < 16; k++) if (st[STAT_STAMPS + k]) fprintf(stderr, " %s %.1f |", nm[k], 100.0 * (double)st[STAT_STAMPS + k] / tot);
-			fprintf(stderr, "\n");
-		}
 	}
 	return BWB_OK;
 }

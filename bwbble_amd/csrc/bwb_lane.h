@@ -262,6 +262,15 @@ template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, P L,
 	l.tL = L; l.tU = U; l.T++;
 }
 
+/* A read is finished: its status, hit count, offset and hit-log records are published BEFORE the slot's counter moves.  The
+ * host polls that counter and copies the results on another stream while this kernel may still be running (a slot's parked reads
+ * finish inside the NEXT slot's slice): plain stores can sit dirty in this XCD's L2 until the end of the kernel, so a release
+ * fence (L2 write-back) comes first.  Once per read (tens of thousands of iterations): its cost does not show. */
+__device__ __forceinline__ void publish_done(unsigned int *done) {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+	atomicAdd(done, 1u);
+}
+
 __device__ __forceinline__ uint32_t grab_read(const Work &wk) {
 	const uint32_t w = atomicAdd(wk.counter, 1u); /* the compiler folds this into one atomic per wave */
 	if (w >= wk.n_work) return NONE32;
@@ -578,6 +587,21 @@ template <typename P, bool WIDE> struct LHeap {
 #define STAMP(k) do { } while (0)
 #endif
 
+/* Diagnostic build (`make hist`, tools_exp/libbwbble_hip_hist.so): wave-aggregated event counters of the search loop - what the
+ * iterations are (expansion / exact step / pruned / hit), how wide the expanded intervals are, how many children they have, what
+ * is pushed where.  HIST(k, cond) counts the lanes for which cond holds; HISTW(k, v) adds a wave-uniform value.  Off in the product. */
+#ifdef BWB_HIST
+#define HIST(k, cond) do { hist[k] += (unsigned long long)__popcll(__ballot(cond)); } while (0)
+#define HISTW(k, v) do { hist[k] += (unsigned long long)(v); } while (0)
+#else
+#define HIST(k, cond) do { } while (0)
+#define HISTW(k, v) do { } while (0)
+#endif
+enum { H_ITER = 0, H_POP, H_POP_FROM_MIRROR, H_POP_GAPPED, H_PRUNED, H_HIT, H_EXACT_START, H_EXPAND, H_EXACT_STEP, H_NEED_RANK, H_SAME_BKT, H_TWO_BKT,
+       H_W1, H_W2, H_W4, H_W8, H_W32, H_W128, H_WBIG, H_NE0, H_NE1, H_NE2, H_NE3_4, H_NE5_8, H_NE9, H_PUSH_GAP, H_PUSH_MIS, H_PUSH_MATCH,
+       H_DEL_OK, H_MM_OK, H_INS_OK, H_TOP_RELOAD, H_WAVE_ITERS, H_WAVE_GAPLOOP, H_WAVE_MISLOOP, H_WAVE_MATCHLOOP, H_WAVE_ANY_TWO_BKT, H_WAVE_ANY_WIDE8,
+       H_WAVE_NREQ_LE16, H_ALPHA, H_EXACT_MULTI, H_FINISH, H_ALLOC, H_WAVE_ANY_EXACT, H_WAVE_ANY_EXPAND, H_WAVE_ALL_EXACT, H_EXP_SAME_W1, H_EXP_SAME_W2_4, H_N };
+
 /* Slices.  One launch of kl_search = one slice of the stream of batches.  Per-read work is heavy-tailed, so a
  * launch that runs until its last read is done ends with ever fewer busy lanes.  Instead, when the cursor of the batch runs
  * out (wk.suspend) a wave whose lane could not get a new read PARKS the reads its other lanes are working on - every
@@ -641,6 +665,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef BWB_HIST
+	unsigned long long hist[H_N] = { 0 };
+	unsigned long long hl_gap = 0, hl_mis = 0, hl_match = 0; /* per-lane sums */
 #endif
 	uint4 *const mysave = sc.save + (size_t)slot * SAVE_U4;
 	if (wk.resume && (mysave[0].x & 1u)) {
@@ -744,7 +772,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					if (ovf0) b.status[rid] = ST_SCRATCH_OVF;
 					descs[wk.slot].out.n[rid] = 0; h.release_excess(); active = false;
 					__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					atomicAdd(descs[wk.slot].done, 1u);
+					publish_done(descs[wk.slot].done);
 				}
 			}
 		}
@@ -784,6 +812,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		int widx = 0;
 		if (active) { n_iter++; r_iter++; }
 		w_iter++;
+		HIST(H_ITER, active); HISTW(H_WAVE_ITERS, 1);
+#ifdef BWB_HIST
+		int hw_g = 0, hw_x = 0, hw_0 = 0; bool h_mirror = false;
+#endif
 
 		/* add_alignment (align.c:271-298) into the lane's private hit list */
 		auto add_aln = [&](P L, P U, int score, int alen) {
@@ -808,6 +840,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			else {
 				const int bk = h.best(nb);
 				h.switch_cache(bk);
+#ifdef BWB_HIST
+				h_mirror = h.top_valid;
+#endif
 				h.pop(e); /* heap_pop :594-610: the top of the best bucket, usually straight from its register mirror */
 				e_score = bk;
 				r_pop++;
@@ -831,6 +866,19 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			need_rank = true;
 		}
 
+#ifdef BWB_HIST
+		HIST(H_POP, active && mode == LMODE_POP && (from_pop || finish)); HIST(H_POP_GAPPED, from_pop && ((e.f >> 16) != 0)); HIST(H_POP_FROM_MIRROR, from_pop && h_mirror);
+		HIST(H_EXACT_STEP, active && mode == LMODE_EXACT); HIST(H_NEED_RANK, need_rank); HIST(H_ALPHA, need_rank && alpha);
+		HIST(H_EXACT_MULTI, active && mode == LMODE_EXACT && curT > 1);
+		const P hw_ = (P)(iU - iL + 1);
+		const bool hsame_ = need_rank && ((P)(iL - 1) >> 7) == (iU >> 7) && iL != 0 && iU != last_row;
+		HIST(H_SAME_BKT, hsame_); HIST(H_TWO_BKT, need_rank && !hsame_);
+		HIST(H_W1, need_rank && hw_ == 1); HIST(H_W2, need_rank && hw_ == 2); HIST(H_W4, need_rank && hw_ > 2 && hw_ <= 4); HIST(H_W8, need_rank && hw_ > 4 && hw_ <= 8);
+		HIST(H_W32, need_rank && hw_ > 8 && hw_ <= 32); HIST(H_W128, need_rank && hw_ > 32 && hw_ <= 128); HIST(H_WBIG, need_rank && (hw_ > 128 || hw_ == 0));
+		HISTW(H_WAVE_ANY_TWO_BKT, __any(need_rank && !hsame_) ? 1 : 0); HISTW(H_WAVE_ANY_WIDE8, __any(need_rank && (hw_ > 8 || hw_ == 0)) ? 1 : 0);
+		HISTW(H_WAVE_ANY_EXACT, __any(active && mode == LMODE_EXACT) ? 1 : 0); HISTW(H_WAVE_ANY_EXPAND, __any(from_pop && need_rank) ? 1 : 0);
+		HISTW(H_WAVE_ALL_EXACT, __all(!active || mode == LMODE_EXACT) ? 1 : 0);
+#endif
 		STAMP(1);
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
 		uint32_t wd = 0, ws = 0, ne = 0;
@@ -854,6 +902,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
 		}
 		STAMP(2);
+		HISTW(H_WAVE_NREQ_LE16, nreq <= COOP_MAX_REQ ? 1 : 0);
 		if (nreq > COOP_MAX_REQ) {
 			LaneReq<P> ra, rb;
 			n_bkt += wave_fetch_pair<P>(buckets, last_row, need_rank, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
@@ -889,6 +938,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			bool pruned = diff_left < 0;                                                                  /* :313 */
 			if (!pruned && e_i > 0 && diff_left < (int)(wd & 127u)) pruned = true;                        /* :317 */
 			if (!pruned && seed_index > 0 && diff_left_seed < (int)(ws & 127u)) pruned = true;            /* :326 */
+#ifdef BWB_HIST
+			HIST(H_PRUNED, pruned); HIST(H_HIT, !pruned && e_i == 0); HIST(H_EXACT_START, !pruned && e_i != 0 && diff_left == 0);
+			HIST(H_EXPAND, !pruned && e_i != 0 && diff_left != 0);
+			HIST(H_EXP_SAME_W1, !pruned && e_i != 0 && diff_left != 0 && hsame_ && hw_ == 1); HIST(H_EXP_SAME_W2_4, !pruned && e_i != 0 && diff_left != 0 && hsame_ && hw_ >= 2 && hw_ <= 4);
+#endif
 			if (!pruned) {
 				if (e_i == 0) { /* hit :331-344 */
 					if (n_alns == 0) {
@@ -936,6 +990,12 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
 					const int nG = __popc(gapm), nX = __popc(mism), n0 = __popc(matchm);
 					r_push += nG + nX + n0;
+#ifdef BWB_HIST
+					{ const int nne = __popc(ne);
+					  HIST(H_NE0, nne == 0); HIST(H_NE1, nne == 1); HIST(H_NE2, nne == 2); HIST(H_NE3_4, nne == 3 || nne == 4); HIST(H_NE5_8, nne >= 5 && nne <= 8); HIST(H_NE9, nne >= 9);
+					  HIST(H_DEL_OK, del_ok); HIST(H_MM_OK, mm_ok); HIST(H_INS_OK, ins_ok);
+					  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nG; hl_mis += nX; hl_match += n0; }
+#endif
 					/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
 					const int tX = scX == sc0 ? 0 : 1, tG = scG == sc0 ? 0 : (scG == scX ? tX : 2);
 					const int k0 = n0 + (tX == 0 ? nX : 0) + (tG == 0 ? nG : 0);
@@ -1024,6 +1084,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			}
 		}
 
+#ifdef BWB_HIST
+		{ int t_ = hw_g; for (int o_ = 32; o_; o_ >>= 1) t_ = max(t_, __shfl_xor(t_, o_)); HISTW(H_WAVE_GAPLOOP, t_);
+		  t_ = hw_x; for (int o_ = 32; o_; o_ >>= 1) t_ = max(t_, __shfl_xor(t_, o_)); HISTW(H_WAVE_MISLOOP, t_);
+		  t_ = hw_0; for (int o_ = 32; o_; o_ >>= 1) t_ = max(t_, __shfl_xor(t_, o_)); HISTW(H_WAVE_MATCHLOOP, t_); }
+#endif
 		STAMP(4);
 		if (exact_step && need_rank) {
 			bool exact_done = false;
@@ -1097,12 +1162,14 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		}
 
 		STAMP(15);
+		HIST(H_TOP_RELOAD, active && !h.top_valid && h.cst != NONE32);
 		if (active && !h.top_valid && h.cst != NONE32) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
 			h.load_entry(h.cst, h.top);
 			h.top_valid = true;
 		}
 		STAMP(5);
 		if (ovf) finish = true;
+		HIST(H_FINISH, finish);
 		if (finish) {
 			const SlotDesc &d = descs[myslot]; /* (the read may belong to an earlier slot than the one this launch feeds from) */
 			const OutBuf out = d.out;
@@ -1118,7 +1185,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			d.b.status[rid] = ovf ? ST_SCRATCH_OVF : (outovf ? ST_OUT_OVF : ST_OK);
 			if (d.b.dbg_iters) d.b.dbg_iters[rid] = r_iter;
 			if (!ovf && !outovf) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
-			atomicAdd(d.done, 1u);
+			publish_done(d.done);
 			/* leave every bucket state empty for the next read and give its chunks back */
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_sum, (h.pused + h.xcnt + 15u) >> 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1141,6 +1208,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[STAT_WAVE_ITERS], w_iter); /* debug: wave iterations */
 #ifdef BWB_STAMPS
 	if (n_iter) for (int k = 0; k < 16; k++) atomicAdd(&stats[STAT_STAMPS + k], seg[k]);
+#endif
+#ifdef BWB_HIST
+	hist[H_PUSH_GAP] = 0; hist[H_PUSH_MIS] = 0; hist[H_PUSH_MATCH] = 0;
+	if ((threadIdx.x & 63u) == 0) for (int k = 0; k < H_N; k++) if (hist[k]) atomicAdd(&stats[STAT_HIST + k], hist[k]);
+	if (hl_gap) atomicAdd(&stats[STAT_HIST + H_PUSH_GAP], hl_gap);
+	if (hl_mis) atomicAdd(&stats[STAT_HIST + H_PUSH_MIS], hl_mis);
+	if (hl_match) atomicAdd(&stats[STAT_HIST + H_PUSH_MATCH], hl_match);
 #endif
 	if (!parked) mysave[0].x = 0u;
 	/* the last wave of the block to leave hands the block's recycle stack to the next slice */

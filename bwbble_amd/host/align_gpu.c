@@ -39,6 +39,7 @@ typedef struct {
 	size_t n_chunks;
 	atomic_size_t *cursor;
 	chunk_res_t *res;
+	const size_t *carry_src; /* per chunk: the last read before it that computes a D_seed (SIZE_MAX: none) */
 	bwb_stats total;
 	double kernel_ms;
 } worker_t;
@@ -82,13 +83,7 @@ static void *gpu_worker(void *arg) {
 		 * head of the chunk sees its bounds, like in the reference's serial loop (inexact_match.c:35,62-65) */
 		const uint8_t *carry = NULL;
 		uint32_t carry_len = 0;
-		for (size_t q = r0; q-- > 0 && r0 - q <= 4096;) { /* (bounded look-back; a FASTQ of nothing but short reads has no source anyway) */
-			const uint32_t lq = w->reads->len[q];
-			const uint8_t *sq = w->reads->seq + q * w->reads->stride;
-			int ok = w->params->seed_length && lq > (uint32_t)w->params->seed_length && lq <= 255;
-			if (ok && w->params->use_precalc) { if (lq < 12) ok = 0; for (int k = 0; ok && k < 12; k++) if (sq[k] > 3) ok = 0; }
-			if (ok) { carry = sq; carry_len = lq; break; }
-		}
+		if (w->carry_src[c] != SIZE_MAX) { carry = w->reads->seq + w->carry_src[c] * w->reads->stride; carry_len = w->reads->len[w->carry_src[c]]; }
 		if (bwb_hip_slot_upload(ctx, slot, w->params, w->reads->seq + r0 * w->reads->stride, w->reads->len + r0, n, w->reads->stride, carry, carry_len) ||
 		    bwb_hip_slot_submit(ctx, slot))
 			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
@@ -136,12 +131,26 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_interva
 	if (chunk < 1) chunk = 1;
 	const size_t n_chunks = (reads->count + (size_t)chunk - 1) / chunk;
 	chunk_res_t *res = (chunk_res_t *)calloc(n_chunks ? n_chunks : 1, sizeof(chunk_res_t));
+	/* One pass over the whole file (the serial reference's look-back has no bound, inexact_match.c:35,62-65): for every chunk, the
+	 * last read before it that is longer than the seed and not dropped by -P. */
+	size_t *carry_src = (size_t *)malloc((n_chunks ? n_chunks : 1) * sizeof(size_t));
+	{
+		size_t last = SIZE_MAX;
+		for (size_t q = 0; q < reads->count; q++) {
+			if (q % chunk == 0) carry_src[q / chunk] = last;
+			const uint32_t lq = reads->len[q];
+			const uint8_t *sq = reads->seq + q * reads->stride;
+			int ok = params->seed_length && lq > (uint32_t)params->seed_length && lq <= 255;
+			if (ok && params->use_precalc) { if (lq < 12) ok = 0; for (int k = 0; ok && k < 12; k++) if (sq[k] > 3) ok = 0; }
+			if (ok) last = q;
+		}
+	}
 	atomic_size_t cursor = 0;
 	worker_t *ws = (worker_t *)calloc((size_t)n_gpus, sizeof(worker_t));
 	pthread_t *th = (pthread_t *)calloc((size_t)n_gpus, sizeof(pthread_t));
 	const double t0 = wall();
 	for (int g = 0; g < n_gpus; g++) {
-		ws[g] = (worker_t){ .gpu = g, .device = nmap ? devmap[g] : g, .BWT = BWT, .reads = reads, .params = params, .chunk = chunk, .n_chunks = n_chunks, .cursor = &cursor, .res = res };
+		ws[g] = (worker_t){ .gpu = g, .device = nmap ? devmap[g] : g, .BWT = BWT, .reads = reads, .params = params, .chunk = chunk, .n_chunks = n_chunks, .cursor = &cursor, .res = res, .carry_src = carry_src };
 		if (pthread_create(&th[g], NULL, gpu_worker, &ws[g])) bwb_die("align_reads_inexact_gpu: cannot start a host thread");
 	}
 	/* ordered writer (the reference writes after each batch, inexact_match.c:154-162) */
@@ -166,7 +175,7 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_interva
 	printf("GPUs: %d  reads: %u  wall: %.3f sec (%.0f reads/s incl. index upload)  kernel: %.1f ms  rank-block visits: %llu  hits: %llu  re-run reads: %llu\n",
 	       n_gpus, reads->count, dt, reads->count / (dt > 0 ? dt : 1), kms, (unsigned long long)(tot.visits_single + tot.visits_alphabet),
 	       (unsigned long long)tot.n_alignments, (unsigned long long)tot.n_overflow_reads);
-	free(ws); free(th); free(res);
+	free(ws); free(th); free(res); free(carry_src);
 	fclose(alnFile);
 	return 0;
 }

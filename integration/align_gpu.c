@@ -100,7 +100,7 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, sa_intv_list_t *precalc_
 		 * (the serial reference's one D_seed buffer, inexact_match.c:35,62-65): hand that read over */
 		const char *carry = NULL;
 		unsigned carry_len = 0;
-		for (unsigned q = submitted; q-- > 0 && submitted - q <= 4096;) {
+		for (unsigned q = submitted; q-- > 0;) { /* (no bound: the serial reference has none; stops at the first longer read) */
 			const read_t *r = &reads->reads[q];
 			int ok = params->seed_length && r->len > params->seed_length && r->len <= 255;
 			if (ok && params->use_precalc && (r->len < PRECALC_INTERVAL_LENGTH || read2index(r->rc, r->len) < 0)) ok = 0; /* dropped before calculate_d (:50-57) */

@@ -160,6 +160,39 @@ def test_streamed_slots_match_oracle(mid_ctx, oracle):
     check(ctx, oracle, idx, ["-n", "2"], seqs[:800], lens[:800])
 
 
+def test_streamed_results_are_published_before_the_host_reads_them(mid_ctx):
+    """Long slices: a slot's parked reads finish INSIDE the next slot's slice, and the host fetches status, counts, offsets and
+    the hit log on another stream while that kernel is still running.  The kernel publishes a read's results (release fence)
+    before it moves the slot's counter (publish_done, bwb_lane.h); here every chunk of a 2 M-read stream must equal what the
+    one-batch interface - which reads back only after every kernel has ended - gives for the same reads."""
+    d, fa, ctx, idx = mid_ctx
+    B, nbatch = 250000, 8
+    seqs, lens = synth_reads(fa, str(d / "pub.fq"), B * nbatch, 100, 33, sub=1.5, indel=0.5, npct=0.5)
+    p = bw.params(["-n", "3"])
+    want = []
+    for j in range(nbatch):
+        off, alns = ctx.align(p, seqs[j * B:(j + 1) * B], lens[j * B:(j + 1) * B])
+        want.append(bw.aln_bytes(off, alns))
+    ctx.flush()
+    ctx.reset_stats()
+    got = [None] * nbatch
+    nslot = 3
+    for j in range(nbatch):
+        slot = j % nslot
+        if j >= nslot:
+            off, alns = ctx.slot_result(slot)
+            got[j - nslot] = bw.aln_bytes(off, alns)
+        ctx.slot_upload(slot, p, seqs[j * B:(j + 1) * B], lens[j * B:(j + 1) * B])
+        ctx.slot_submit(slot)
+    for j in range(nbatch - nslot, nbatch):
+        off, alns = ctx.slot_result(j % nslot)
+        got[j] = bw.aln_bytes(off, alns)
+    ctx.flush()
+    assert [len(g) for g in got] == [len(w) for w in want]
+    assert got == want
+    assert ctx.stats().n_parked_reads > 0
+
+
 def test_unrepresentable_reads_get_empty_records(mid_ctx, oracle):
     """A read longer than 255 bases (aln_entry_t.i is 8-bit, align.h:104) no longer fails the batch: empty record, the others
     exact.  (An EMPTY read is different: like in the reference its root entry is a hit with the whole index as interval.)"""
