@@ -30,10 +30,6 @@
 #include "bwb_kernels.h"
 
 #define LANE_BLOCK 256
-#define KID_STRIDE 64            /* children live in LDS columns of the lane's own wave: child j of lane o at [j * 64 + o] */
-/* LDS of a wave: the staging area of the cooperative bucket gather (2 sides x 64 buckets x 128 bytes), re-used for the children
- * once the buckets are in registers (2 x 16 rows x 64 lanes x 4 or 8 bytes <= 16 KB) */
-#define WAVE_LDS_BYTES (2 * 64 * 128)
 /* lane-private LDS columns: explicit LDS address space, so they compile to ds_read/ds_write (a generic or volatile
  * pointer here turns every access into a flat_* instruction with 64-bit addresses and full waits) */
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
@@ -63,188 +59,240 @@ struct LaneScratch {
 	uint32_t nslots, lcap, acap, wstride;
 };
 
-/* ---- per-lane rank: C[j] + Occ(j,pos) for j = 1..15 -------------------------------------------- */
-template <typename P> struct LaneReq {
-	P pos;
-	bool regular;
-	int row;
-	uint4 d[8];
-};
+/* ---- per-lane rank from the wave's LDS staging area ------------------------------------------------------------------------
+ *
+ * LDS of a wave (WAVE_LDS_BYTES = 12.5 KB; three blocks of four waves fit a CU's 160 KB):
+ *   [0, 8 KB)        64 rows of 128 bytes, one per lane.  During the gather: the bucket of position L-1 of the lane ("L row").
+ *                    After the rank: the lane's CHILDREN in relative form - 16 + 16 words: relL[j], relU[j] = #j in
+ *                    BWT[superblock start .. L-1] resp. [.. U] (the same 32-bit counts a bucket stores, plus the block's share),
+ *                    so that child j = [base[rowL][j] + relL[j] + 1, base[rowU][j] + relU[j]] (kid_get).  A visit needs the
+ *                    interval of one or two children (a match, now and then a mismatch; deletions travel as one group entry),
+ *                    so the 15 x 2 positions are no longer materialised: round 2 wrote 30 of them per visit.
+ *   [8 KB, 12 KB)    NU_MAX rows: the bucket of position U of the lanes whose U falls into ANOTHER bucket, compacted (one pair
+ *                    in six at GRCh37 scale: 11 of 64 lanes on average; when more than NU_MAX lanes of a wave need one, the rest
+ *                    are fetched in a further round)
+ *   [12 KB, 12.5 KB) the exchange array of the gather
+ * A rank is computed straight from the LDS rows, one 32-character sub-block at a time (four plane words in registers, not the
+ * 2 x 32 words of both buckets as in round 2: the two kernels' register budgets are what allows three waves per SIMD). */
+#define NU_MAX 32
+#define WAVE_STAGE_U4 (64 * 8 + NU_MAX * 8)
+#define WAVE_XCH_OFF (WAVE_STAGE_U4 * 16)
+#define WAVE_LDS_BYTES (WAVE_XCH_OFF + 512)
+/* block-level LDS in front of the waves' areas: the base table, then one all-zero 128-byte row that stands in for the bucket of a
+ * position that needs none (-1, length-1, an idle lane): counts 0, no characters */
+#define LDS_ZERO_OFF (BWB_BASE_ROWS * 16 * 8)
+#define LDS_WAVES_OFF (LDS_ZERO_OFF + 128)
 
-/* Cooperative gather: one 128-byte bucket per lane, loaded by the whole wave.  Instruction r fetches the buckets of lanes
- * 8r .. 8r+7: lane l loads slice (l & 7) of the bucket of lane 8r + (l >> 3), so a wave instruction touches 8 lines of
- * 128 contiguous bytes instead of 64 different ones, and the slices reach their owner through the wave's LDS staging area.
- * Measured on a 7 GiB table (tools_exp/gather_bench.hip, profiles/r2_gather_shape.txt): 50 G buckets/s (6.4 TB/s) this
- * way against 10.9 G/s (1.4 TB/s) when every lane loads its own bucket with 8 x dwordx4 - at GRCh37 scale the per-lane shape is
- * bound by address translation, 64 different pages per instruction, not by HBM.  Called by EVERY lane of the wave
- * (blk == NONE32: this lane wants nothing; it still loads for the others). */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
+typedef __attribute__((address_space(3))) unsigned char *LdsBytes;
+
 /* cache policy of the bucket loads (aux operand: 1 = sc0, 2 = nt, 16 = sc1).  A non-temporal policy, meant to keep the per-lane
- * metadata in L2, measured 2 % slower at 884 M rows (tools/r2_probe5.sh): left at the default. */
+ * metadata in L2, measured 2 % slower at 884 M rows (round 2): left at the default. */
 #ifndef BWB_GATHER_AUX
 #define BWB_GATHER_AUX 0
 #endif
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
+#define QUIRK_CODES 0x2A20u /* codes 5, 9, 11, 13: not counted by O_alphabet (bwt.c:718-726) */
 
-/* Both sides of an SA interval for every lane of the wave.  `need`: this lane wants a rank at pL and pU.  When L-1 and U fall
- * into the same bucket (narrow intervals: most of them) it is fetched once.  Returns the number of buckets fetched for this
- * lane.
- * The 16 loads (8 rounds x 2 sides) are global_load_lds_dwordx4: memory -> LDS without a register in between, all in flight
- * together.  Such a load writes LDS at base + 16 * lane, so round r fills 1 KB = rows of the owners 8r .. 8r+7; to keep the
- * owners' 128-bit reads off each other's banks the slices of owner o are rotated by (o >> 1) & 7 - on the SOURCE side (the lane
- * at position p of owner o's row loads slice (p - rot) & 7), which is the only side such a load lets one choose.
- * The staging area is free again (for the children) when this returns. */
+template <typename P> __device__ __forceinline__ bool pi_regular(P last_row, P pos) { return !(pos == (P)~(P)0 || pos == last_row); }
+
+/* what a lane knows about its pair of positions */
+template <typename P> struct PairInfo {
+	int offL, offU;        /* position & 127 */
+	int rowL, rowU;        /* base-table rows */
+	bool regL, regU;       /* false for -1 / length-1 (no bucket: the base row is the answer) */
+	bool same;             /* both regular, one bucket */
+	uint32_t blkL, blkU;   /* bucket to fetch for either side, NONE32 = none (block numbers fit 32 bits: 2^34 characters / 128) */
+	uint32_t ku;           /* this lane's rank among the lanes of the wave that fetch a U row (NONE32: it fetches none) */
+	int nU;                /* how many lanes of the wave do */
+};
 template <typename P>
-__device__ __forceinline__ uint32_t wave_fetch_pair(const uint4 *__restrict__ buckets, P last_row, bool need, P pL, P pU, LaneReq<P> &ra, LaneReq<P> &rb,
-                                                    Lds<u32x4> stage, int lane) {
-	ra.pos = pL; rb.pos = pU;
+__device__ __forceinline__ void pair_setup(P last_row, bool need, P pL, P pU, int lane, PairInfo<P> &pi) {
 	const bool negL = (pL == (P)~(P)0), endL = (pL == last_row), negU = (pU == (P)~(P)0), endU = (pU == last_row);
-	ra.regular = !(negL || endL); rb.regular = !(negU || endU);
-	const P blkL = pL >> 7, blkU = pU >> 7;
-	ra.row = negL ? BWB_ROW_NEG : (endL ? BWB_ROW_END : (int)((uint64_t)blkL >> BWB_SB_SHIFT));
-	rb.row = negU ? BWB_ROW_NEG : (endU ? BWB_ROW_END : (int)((uint64_t)blkU >> BWB_SB_SHIFT));
-	const bool same = ra.regular && rb.regular && blkL == blkU;
-	const bool wantL = need && ra.regular, wantU = need && rb.regular && !same;
-	const uint32_t myL = wantL ? (uint32_t)blkL : NONE32, myU = wantU ? (uint32_t)blkU : NONE32; /* (block numbers fit 32 bits: 2^34 characters / 128) */
+	pi.regL = !(negL || endL); pi.regU = !(negU || endU);
+	pi.offL = (int)(pL & 127); pi.offU = (int)(pU & 127);
+	const P bL = pL >> 7, bU = pU >> 7;
+	pi.rowL = negL ? BWB_ROW_NEG : (endL ? BWB_ROW_END : (int)((uint64_t)bL >> BWB_SB_SHIFT));
+	pi.rowU = negU ? BWB_ROW_NEG : (endU ? BWB_ROW_END : (int)((uint64_t)bU >> BWB_SB_SHIFT));
+	pi.same = need && pi.regL && pi.regU && bL == bU;
+	const bool wantL = need && pi.regL, wantU = need && pi.regU && !pi.same;
+	pi.blkL = wantL ? (uint32_t)bL : NONE32; pi.blkU = wantU ? (uint32_t)bU : NONE32;
+	const unsigned long long maskU = __ballot(wantU);
+	pi.nU = __popcll(maskU);
+	pi.ku = wantU ? (uint32_t)__popcll(maskU & ((1ull << lane) - 1ull)) : NONE32;
+}
+
+/* Cooperative gather: one 128-byte bucket per lane and side, loaded by the whole wave.  Instruction r fetches the buckets of the
+ * owners 8r .. 8r+7: lane l loads slice (l & 7) of the bucket of owner 8r + (l >> 3), so a wave instruction touches 8 lines of
+ * 128 contiguous bytes instead of 64 different ones (measured on a 7 GiB table: 50 G buckets/s this way against 10.9 G/s when every
+ * lane loads its own bucket with 8 x dwordx4 - that shape is bound by address translation, 64 pages per instruction).  The loads
+ * are global_load_lds_dwordx4: memory -> LDS without a register in between, all in flight together; such a load writes LDS at
+ * base + 16 * lane, so to keep the owners' 128-bit reads off each other's banks the slices of row o are rotated by (o >> 1) & 7 on
+ * the SOURCE side.  Which bucket an owner wants travels through the wave's exchange array (written transposed, so that a lane reads
+ * the 8 owners of its column with 128-bit reads; round 2 used 16 ds_bpermute).
+ * Round `first` == 0 fetches the L rows and the U rows of the compacted owners [0, NU_MAX); a later round (first = NU_MAX, ...)
+ * only the U rows of the owners [first, first + NU_MAX).  Called by EVERY lane of the wave. */
+template <typename P>
+__device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, const PairInfo<P> &pi, int first, Lds<u32x4> stage, int lane) {
 	const int sub = lane >> 3, p = lane & 7;
-	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the children of the previous iteration (same LDS) have been read */
-	uint32_t oL[8], oU[8]; /* the 16 exchanges first (one wait), then the 16 loads back to back */
-#pragma unroll
-	for (int r = 0; r < 8; r++) { oL[r] = (uint32_t)__shfl((int)myL, 8 * r + sub); oU[r] = (uint32_t)__shfl((int)myU, 8 * r + sub); }
+	Lds<uint32_t> xch = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF); /* [0,64): L owners, [64,128): U owners, both transposed: owner o at (o & 7) * 8 + (o >> 3) */
+	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU_MAX;
+	const uint32_t k = pi.ku - (uint32_t)first;
+	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL;
+	xch[64 + lane] = NONE32;
+	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU;
+	u32x4 a0 = { NONE32, NONE32, NONE32, NONE32 }, a1 = a0;
+	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
+	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
+	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the owners are in registers, and whatever was read from the rows before (the children of
+	                                       the previous iteration, the previous round's U rows) is too */
+	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
 		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oL[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 64 * r), 16, 0, BWB_GATHER_AUX);
+	}
+	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
+#pragma unroll
+	for (int r = 0; r < NU_MAX / 8; r++) {
+		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
 		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oU[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 512 + 64 * r), 16, 0, BWB_GATHER_AUX);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the slices have landed in LDS */
 	__builtin_amdgcn_wave_barrier();
-	const int rot = lane >> 1;
-	/* (a lane that wants nothing, or whose position is one of the two special ones, reads whatever its row holds: the values
-	 * are only used under `regular`; a same-bucket pair reads the one row twice instead of copying 32 registers) */
-	const Lds<u32x4> mineL = stage + lane * 8, mineU = mineL + (wantU ? 512 : 0);
-#pragma unroll
-	for (int k = 0; k < 8; k++) { const u32x4 v = mineL[(k + rot) & 7]; ra.d[k] = make_uint4(v.x, v.y, v.z, v.w); }
-#pragma unroll
-	for (int k = 0; k < 8; k++) { const u32x4 v = mineU[(k + rot) & 7]; rb.d[k] = make_uint4(v.x, v.y, v.z, v.w); }
-	__builtin_amdgcn_s_waitcnt(0xc07f); /* the buckets are in registers before the children overwrite the staging area */
-	return (wantL ? 1u : 0u) + (wantU ? 1u : 0u);
 }
 
-/* pop[j] = #j in the bucket's block at offsets [0, pos & 127], j = 1..15 */
-template <typename P>
-__device__ __forceinline__ void lane_pops(const LaneReq<P> &r, uint32_t pop[16]) {
-#pragma unroll
-	for (int c = 0; c < 16; c++) pop[c] = 0;
-	const int off = (int)(r.pos & 127);
+/* acc[j] += #j among the characters [lo, hi] of the block whose planes are in `row` (slices 4-7, slice k at row[(k + rot) & 7]),
+ * j = 1..15; acc[] is in the order of a bucket's count slices: acc[4 s + t] <-> code {2s, 2s+1, 2s+8, 2s+9}[t].
+ * `first` = code of the block's first character (bwt.c:780).  One sub-block at a time: 4 plane words live. */
+__device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[16], uint32_t &first) {
 #pragma unroll
 	for (int w = 0; w < 4; w++) {
-		const uint4 p = r.d[4 + w];
-		const int nv = off + 1 - 32 * w;
-		const uint32_t m = nv <= 0 ? 0u : (nv >= 32 ? 0xFFFFFFFFu : ((1u << nv) - 1u));
+		const u32x4 p = row[(4 + w + rot) & 7];
+		if (w == 0) first = (p.x & 1u) | ((p.y & 1u) << 1) | ((p.z & 1u) << 2) | ((p.w & 1u) << 3);
+		const int nh = hi + 1 - 32 * w, nl = lo - 32 * w; /* characters [0, nh) minus [0, nl) of this sub-block */
+		const uint32_t mh = nh <= 0 ? 0u : (nh >= 32 ? 0xFFFFFFFFu : ((1u << nh) - 1u));
+		const uint32_t ml = nl <= 0 ? 0u : (nl >= 32 ? 0xFFFFFFFFu : ((1u << nl) - 1u));
+		const uint32_t m = mh & ~ml;
 		const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
 		const uint32_t m2 = m & ~p.z, m2p = m & p.z;
 		const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
 #pragma unroll
-		for (int c = 1; c < 16; c++) pop[c] += __popc(a[c & 3] & b[c >> 2]);
+		for (int c = 1; c < 16; c++) {
+			const int s = (c & 7) >> 1, t = (c & 1) + 2 * (c >> 3);
+			acc[4 * s + t] += __popc(a[c & 3] & b[c >> 2]);
+		}
+		__builtin_amdgcn_sched_barrier(0); /* (keeps the four sub-blocks apart: interleaved they need 4 x the registers) */
 	}
 }
-/* C[j] + Occ(j, pos) from the bucket counts (slice s: {cnt[2s], cnt[2s+1], cnt[2s+8], cnt[2s+9]}) */
-template <typename P>
-__device__ __forceinline__ P lane_val(const LaneReq<P> &r, const P *brow, const uint32_t pop[16], int j) {
-	const int s = (j & 7) >> 1, comp = (j & 1) + 2 * (j >> 3); /* compile-time after unrolling: no pointer into r.d, so that
-	                                                              the buckets stay in registers */
-	const uint4 q = r.d[s];
-	const uint32_t cw = comp == 0 ? q.x : (comp == 1 ? q.y : (comp == 2 ? q.z : q.w));
-	return brow[j] + (r.regular ? (P)(cw + pop[j]) : (P)0);
+/* index of code j in the count-slice order */
+__device__ __forceinline__ constexpr int cslot(int j) { return 4 * ((j & 7) >> 1) + (j & 1) + 2 * (j >> 3); }
+
+/* where a lane's children are after wave_children */
+template <typename P> struct KidCtx {
+	Lds<uint32_t> row;     /* the lane's row: relL in slices 0-3, relU in slices 4-7 (count-slice order, rotated) */
+	int rot;
+	Lds<P> baseL, baseU;   /* base-table rows of the two positions */
+	bool qL, qU;           /* O_alphabet's view of the codes 5, 9, 11, 13 applies to this side: value = C[j] - [first char of the block == j] */
+};
+/* child j = [vL(j) + 1, vU(j)] */
+template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &kc, Lds<P> s_base, int j, P &L, P &U) {
+	const int s = (j & 7) >> 1, t = (j & 1) + 2 * (j >> 3);
+	const uint32_t rl = kc.row[4 * ((s + kc.rot) & 7) + t], ru = kc.row[4 * ((4 + s + kc.rot) & 7) + t];
+	const bool qz = ((QUIRK_CODES >> j) & 1u) != 0;
+	const bool zl = qz && kc.qL, zu = qz && kc.qU; /* rel = 1 - [first == j] then; the base is C[j] - 1 */
+	const Lds<P> cneg = s_base + BWB_ROW_NEG * 16;
+	const P bL = (zl ? cneg : kc.baseL)[j] - (zl ? 1 : 0), bU = (zu ? cneg : kc.baseU)[j] - (zu ? 1 : 0);
+	L = (P)(bL + (P)rl + 1); U = (P)(bU + (P)ru);
 }
 
-#ifndef COOP_MAX_REQ
-#define COOP_MAX_REQ 16 /* lanes of a wave needing a rank at or below which the cooperative (octet) rank is used */
-#endif
-#define KID_ROWS 16
-
-/* Children of the SA interval [iL, iU], staged in LDS (one column per lane): child j = [vL(j) + 1, vU(j)], j = 1..15.
+/* Children of the SA interval [iL, iU] of every lane of the wave: child j = [vL(j) + 1, vU(j)], j = 1..15.
  *   alpha == false: v(j) = C[j] + Occ(j, pos)                                      (O(), bwt.c:348-372)
  *   alpha == true : O_alphabet (bwt.c:374-438): codes 5, 9, 11, 13 are not counted, v(j) = C[j] - [first char of the
  *                   block == j] (bwt.c:427-435,780); exact in the special-cased positions -1 and length-1.
  * Which of the two a visit needs is known before the rank: alpha for an expansion (inexact_match.c:382-383), exact for
- * calculate_d / the exact tail.  Returns the bitmask of non-empty children (bits 1..15). */
+ * calculate_d / the exact tail.  Gathers (every lane of the wave takes part), ranks both sides from LDS, leaves the children
+ * in relative form in the lane's row (kid_get).  Returns the bitmask of non-empty children (bits 1..15); n_bkt += buckets
+ * fetched for this lane.
+ * Side U of a pair that shares its bucket with side L (five in six) is relL + #j among the characters (L-1, U]: the same planes. */
 template <typename P>
-__device__ __forceinline__ uint32_t lane_children(LaneReq<P> &ra, LaneReq<P> &rb, const P *s_base, bool alpha, Lds<P> kidL, Lds<P> kidU) {
-	uint32_t pop[16];
-	const P *cneg = s_base + BWB_ROW_NEG * 16;
-	{ /* L side: value + 1 (inc = 1, inexact_match.c:382) */
-		lane_pops<P>(ra, pop);
-		const P *brow = s_base + ra.row * 16;
-		const uint32_t first = (ra.d[4].x & 1u) | ((ra.d[4].y & 1u) << 1) | ((ra.d[4].z & 1u) << 2) | ((ra.d[4].w & 1u) << 3);
-		const bool q = alpha && ra.regular;
+__device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buckets, P last_row, bool need, P iL, P iU, bool alpha, Lds<P> s_base,
+                                                  Lds<u32x4> stage, Lds<u32x4> zero_row, int lane, uint32_t &n_bkt, KidCtx<P> &kc) {
+	PairInfo<P> pi;
+	pair_setup<P>(last_row, need, (P)(iL - 1), iU, lane, pi);
+	n_bkt += (pi.blkL != NONE32 ? 1u : 0u) + (pi.blkU != NONE32 ? 1u : 0u);
+	wave_gather<P>(buckets, pi, 0, stage, lane);
+	const Lds<u32x4> own = stage + lane * 8;
+	const int rot = (lane >> 1) & 7;
+	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
+	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
+	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
+	uint32_t acc[16];
+	{ /* side L: relL = counts + #j in [0, offL] -> slices 0-3 of the own row */
 #pragma unroll
-		for (int j = 1; j < 16; j++) {
-			P v = lane_val<P>(ra, brow, pop, j);
-			if (j == 5 || j == 9 || j == 11 || j == 13) v = q ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : v;
-			kidL[j * KID_STRIDE] = v + 1;
+		for (int c = 0; c < 16; c++) acc[c] = 0;
+		uint32_t fL = 0;
+		const bool have = pi.blkL != NONE32;
+		block_pops(have ? own : zero_row, have ? rot : 0, 0, pi.offL, acc, fL);
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			u32x4 q = (have ? own : zero_row)[(s + (have ? rot : 0)) & 7];
+			q.x += acc[4 * s]; q.y += acc[4 * s + 1]; q.z += acc[4 * s + 2]; q.w += acc[4 * s + 3];
+			if (kc.qL) { /* (codes 5, 9, 11, 13 are slots {2,1}, {0,3}, {1,3}, {2,3}) */
+				if (s == 2) q.y = fL == 5u ? 0u : 1u;
+				if (s == 0) q.w = fL == 9u ? 0u : 1u;
+				if (s == 1) q.w = fL == 11u ? 0u : 1u;
+				if (s == 2) q.w = fL == 13u ? 0u : 1u;
+			}
+			own[(s + rot) & 7] = q;
 		}
+		__builtin_amdgcn_sched_barrier(0);
 	}
+	/* side U: from the lane's own row (same bucket: relL + the characters in between), from its compacted U row, or nothing to count */
 	uint32_t ne = 0;
-	{
-		lane_pops<P>(rb, pop);
-		const P *brow = s_base + rb.row * 16;
-		const uint32_t first = (rb.d[4].x & 1u) | ((rb.d[4].y & 1u) << 1) | ((rb.d[4].z & 1u) << 2) | ((rb.d[4].w & 1u) << 3);
-		const bool q = alpha && rb.regular;
+	bool rows_differ = false;
+	for (int first = 0;; first += NU_MAX) {
+		if (first > 0) wave_gather<P>(buckets, pi, first, stage, lane); /* (rare: more than NU_MAX lanes of the wave with a second bucket) */
+		const bool fetched = pi.ku != NONE32;
+		const bool now = fetched ? ((int)pi.ku >= first && (int)pi.ku < first + NU_MAX) : first == 0;
+		if (now) {
+			const uint32_t k = pi.ku - (uint32_t)first;
+			const Lds<u32x4> src = fetched ? stage + 512 + k * 8 : (pi.same ? own : zero_row);
+			const int srot = fetched ? (int)((k >> 1) & 7) : (pi.same ? rot : 0);
 #pragma unroll
-		for (int j = 1; j < 16; j++) {
-			P U = lane_val<P>(rb, brow, pop, j);
-			if (j == 5 || j == 9 || j == 11 || j == 13) U = q ? (P)(cneg[j] - (first == (uint32_t)j ? 1 : 0)) : U;
-			kidU[j * KID_STRIDE] = U;
-			ne |= (kidL[j * KID_STRIDE] <= U ? 1u : 0u) << j;
+			for (int c = 0; c < 16; c++) acc[c] = 0;
+			uint32_t fU = 0;
+			block_pops(src, srot, pi.same ? pi.offL + 1 : 0, pi.offU, acc, fU);
+#pragma unroll
+			for (int s = 0; s < 4; s++) {
+				u32x4 q = src[(s + srot) & 7];          /* same bucket: relL (written above); else the U bucket's counts */
+				const u32x4 l = own[(s + rot) & 7];      /* relL */
+				q.x += acc[4 * s]; q.y += acc[4 * s + 1]; q.z += acc[4 * s + 2]; q.w += acc[4 * s + 3];
+				if (kc.qU) {
+					if (s == 2) q.y = fU == 5u ? 0u : 1u;
+					if (s == 0) q.w = fU == 9u ? 0u : 1u;
+					if (s == 1) q.w = fU == 11u ? 0u : 1u;
+					if (s == 2) q.w = fU == 13u ? 0u : 1u;
+				}
+				/* non-empty children, when both positions have the same base row: relU > relL (slot t of slice s is code {2s, 2s+1, 2s+8, 2s+9}[t]) */
+				ne |= (q.x > l.x ? 1u : 0u) << (2 * s) | (q.y > l.y ? 1u : 0u) << (2 * s + 1) | (q.z > l.z ? 1u : 0u) << (2 * s + 8) | (q.w > l.w ? 1u : 0u) << (2 * s + 9);
+				acc[4 * s] = q.x; acc[4 * s + 1] = q.y; acc[4 * s + 2] = q.z; acc[4 * s + 3] = q.w;
+			}
+#pragma unroll
+			for (int s = 0; s < 4; s++) { /* (after every read of the own row's planes) */
+				u32x4 q; q.x = acc[4 * s]; q.y = acc[4 * s + 1]; q.z = acc[4 * s + 2]; q.w = acc[4 * s + 3];
+				own[(4 + s + rot) & 7] = q;
+			}
+		}
+		if (first + NU_MAX >= pi.nU) break;
+	}
+	rows_differ = need && pi.rowL != pi.rowU;
+	if (__any(rows_differ)) { /* a pair that straddles a superblock boundary or has a special position (the root's -1 / length-1): compare positions */
+		if (rows_differ) {
+			ne = 0;
+			for (int j = 1; j < 16; j++) { P L, U; kid_get<P>(kc, s_base, j, L, U); ne |= (L <= U ? 1u : 0u) << j; }
 		}
 	}
-	return ne;
-}
-
-/* Cooperative version for a wave in which at most COOP_MAX_REQ lanes need a rank (the drain phase of a batch, where the
- * kernel time is the serial chain of the heaviest reads): octet k of the wave serves the k-th such lane with the octet
- * rank of bwb_device.h (one coalesced 128-byte load per bucket, ~1/8 of the ALU work per lane) and writes the children
- * straight into the owner's LDS columns.  Executed by all 64 lanes.  Returns the owner's ne mask in the owner lane. */
-template <typename P>
-__device__ __forceinline__ uint32_t coop_children(const uint4 *__restrict__ buckets, P last_row, const P *s_base, unsigned long long rmask,
-                                                  unsigned long long round_mask, int round_base, bool need_rank, bool alpha, P iL, P iU,
-                                                  Lds<P> kids, int lane) {
-	const int k = lane >> 3, ol = lane & 7;
-	unsigned long long m = round_mask; /* requests not yet served: this round takes the 8 lowest */
-#pragma unroll
-	for (int t = 0; t < 7; t++) if (t < k) m &= m - 1;
-	const bool valid = m != 0;
-	const int o = valid ? __ffsll((long long)m) - 1 : 0;                       /* owner lane served by this octet */
-	P pL = oct_bcast((P)(iL - 1), o), pU = oct_bcast(iU, o);
-	const bool oalpha = oct_bcast((uint32_t)alpha, o) != 0;
-	if (!valid) { pL = (P)~(P)0; pU = (P)~(P)0; }
-	RankReq<P> ra, rb;
-	rank_issue<P>(buckets, last_row, pL, ol, ra);
-	rank_issue<P>(buckets, last_row, pU, ol, rb);
-	P a0, a1, u0, u1;
-	uint32_t fL = 0, fU = 0;
-	rank_finish<P, false>(ra, s_base, ol, lane, a0, a1, &fL);
-	rank_finish<P, false>(rb, s_base, ol, lane, u0, u1, &fU);
-	Lds<P> kL = kids + o, kU = kids + KID_ROWS * KID_STRIDE + o; /* the owner's columns (kids = this wave's area) */
-	const int j0 = 2 * ol, j1 = 2 * ol + 1;
-	if (oalpha && (j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13)) { /* O_alphabet's view of the uncounted codes */
-		const P cn = s_base[BWB_ROW_NEG * 16 + j1];
-		if (ra.regular) a1 = (P)(cn - (fL == (uint32_t)j1 ? 1 : 0));
-		if (rb.regular) u1 = (P)(cn - (fU == (uint32_t)j1 ? 1 : 0));
-	}
-	const P L0 = a0 + 1, L1 = a1 + 1;
-	uint32_t bits = 0;
-	if (valid) {
-		if (j0 >= 1) { kL[j0 * KID_STRIDE] = L0; kU[j0 * KID_STRIDE] = u0; bits |= (L0 <= u0 ? 1u : 0u) << j0; }
-		kL[j1 * KID_STRIDE] = L1; kU[j1 * KID_STRIDE] = u1;
-		bits |= (L1 <= u1 ? 1u : 0u) << j1;
-	}
-	bits = oct_or(bits);
-	/* hand the mask to the owner: it is the r-th requesting lane, served in round r/8 by octet r%8 */
-	const int myrank = __popcll(rmask & ((1ull << lane) - 1ull));
-	const uint32_t got = oct_bcast(bits, (myrank & 7) * 8);
-	return (need_rank && (myrank >> 3) == (round_base >> 3)) ? got : 0u;
+	return need ? (ne & 0xFFFEu) : 0u;
 }
 
 /* ---- SA-interval list being built: add_sa_interval (align.c:93-110), tail in registers ------------ */
@@ -286,11 +334,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
 	const int lane = (int)(threadIdx.x & 63u);
-	unsigned char __attribute__((address_space(3))) *wlds = (unsigned char __attribute__((address_space(3))) *)(smem + BWB_BASE_ROWS * 16 * 8) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
-	Lds<u32x4> stage = (Lds<u32x4>)wlds;
-	Lds<P> kids = (Lds<P>)wlds;
+	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
+	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(LdsBytes)(smem + LDS_ZERO_OFF);
+	const Lds<P> sb = (Lds<P>)(LdsBytes)smem; /* the base table again, as an LDS pointer */
+	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
-	Lds<P> kidL = kids + lane, kidU = kids + KID_ROWS * KID_STRIDE + lane;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	Intv<P> *lbase = (Intv<P> *)sc.lists_d + (size_t)slot * 2 * sc.lcap;
 	const int cap = (int)sc.lcap;
@@ -348,18 +396,20 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			}
 		}
 		const bool need = active && c <= 3;
-		LaneReq<P> ra, rb;
-		n_bkt += wave_fetch_pair<P>(buckets, last_row, need, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
+		uint32_t nbk = 0;
+		KidCtx<P> kc;
+		uint32_t ne = wave_children<P>(buckets, last_row, need, iL, iU, false, sb, stage, zero_row, lane, nbk, kc); /* every lane of the wave loads */
+		n_bkt += nbk;
 		if (!active) continue;
 		bool ovf = false;
 		if (c <= 3) {
-			r_vis += (ra.regular ? 1 : 0) + (rb.regular ? 1 : 0);
-			uint32_t ne = lane_children<P>(ra, rb, s_base, false, kidL, kidU);
+			r_vis += (pi_regular(last_row, (P)(iL - 1)) ? 1 : 0) + (pi_regular(last_row, iU) ? 1 : 0);
 			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
 			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
 				const int j = __ffs((int)ne) - 1;
 				ne &= ne - 1;
-				const P L = kidL[j * KID_STRIDE], U = kidU[j * KID_STRIDE];
+				P L, U;
+				kid_get<P>(kc, sb, j, L, U);
 				nm += (int32_t)(uint32_t)(U - L + 1);
 				list_add<P>(nx, L, U, cap, ovf);
 			}
@@ -576,11 +626,31 @@ template <typename P, bool WIDE> struct LHeap {
 	}
 };
 
+/* stores one heap entry at p and advances p */
+template <typename P, bool WIDE>
+__device__ __forceinline__ void emit_entry(uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+	L = pos_enc<P>(L); U = pos_enc<P>(U);
+	if (WIDE) {
+		p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
+		p[1] = make_uint4(f, sa, (uint32_t)runs, (uint32_t)(runs >> 32));
+	} else p[0] = make_uint4((uint32_t)L, (uint32_t)U, f, LHeap<P, WIDE>::pack_w(L, U, sa, (uint32_t)runs));
+	p += WIDE ? 2 : 1;
+}
+
 #define LMODE_POP 0
 #define LMODE_EXACT 1
 #define STATE_M 0 /* align.h:16-18 */
 #define STATE_I 1
 #define STATE_D 2
+/* Heap-only fourth state: a DELETION GROUP.  An expansion that may open or extend a deletion pushes one deletion child per
+ * non-empty code (:448-463) - up to 15 entries that differ in their SA interval only and sit, in sequence, on the gap bucket.
+ * At GRCh37 scale they are more than half of all pushes, and at least five in six are never popped (the search ends first: a gap
+ * costs more than three mismatches).  So the children are not stored: ONE entry with this state, the parent's interval and the
+ * children's fields stands in their place, counted as the children it represents (num_entries, pushes).  When it reaches the top
+ * of its bucket, the lane ranks the parent's interval again and replaces the group by its children - same bucket, same
+ * position, code order - without counting a pop or a visit; from then on they are ordinary STATE_D entries.  LIFO order inside
+ * the bucket, the entry count that max_entries is checked against, and every pop the reference makes are unchanged. */
+#define STATE_GROUP 3
 #ifdef BWB_STAMPS
 #define STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg[k] += t_ - tlast; tlast = t_; } while (0)
 #else
@@ -613,9 +683,9 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
 	const int lane = (int)(threadIdx.x & 63u);
-	unsigned char __attribute__((address_space(3))) *wlds = (unsigned char __attribute__((address_space(3))) *)(smem + BWB_BASE_ROWS * 16 * 8) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
-	Lds<u32x4> stage = (Lds<u32x4>)wlds;
-	Lds<P> kids = (Lds<P>)wlds; /* this wave's children; the same LDS as the staging area of the gather, one after the other */
+	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
+	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(LdsBytes)(smem + LDS_ZERO_OFF);
+	const Lds<P> sb = (Lds<P>)(LdsBytes)smem; /* the base table again, as an LDS pointer */
 	__shared__ unsigned long long s_blockfree;
 	__shared__ unsigned int s_active, s_nfree, s_left; /* reads in flight in this block; chunks on its recycle stack; waves that have left */
 	__shared__ unsigned int s_need_sum, s_need_cnt;    /* chunks (in units of 16) the reads finished by this block took, and how many reads: admission */
@@ -626,8 +696,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		s_nfree = keep ? bs[2] : 0u;
 		s_active = 0; s_left = 0; s_need_sum = 0; s_need_cnt = 0;
 	}
+	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
-	Lds<P> kidL = kids + lane, kidU = kids + KID_ROWS * KID_STRIDE + lane;
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
 	uint4 *myalns = sc.alns + (size_t)slot * sc.acap * 2;
@@ -652,6 +722,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	int r = 0, s = 0, curT = 0, cursel = 0, r_stop = 0;     /* exact-tail state; it ends after rc[r_stop] */
 	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* exact tail: the next interval of a multi-interval list, fetched ahead */
 	bool seeding = false;                                   /* -P: the exact steps under way build the read's first heap entries */
+	uint32_t nxw = 0;                                       /* exact tail: summed width of the intervals added to the next list so far (wrapping, like the
+	                                                           reference's int num_best sum :350-352) */
 	P cL = 0, cU = 0;
 	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
@@ -696,6 +768,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		h.top.L = p64(a11.x, a11.y); h.top.U = p64(a11.z, a11.w);
 		h.top.sa = a12.x; h.top.runsLo = a12.y; h.top.runsHi = a12.z; r_vis_s = a12.w;
 		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z; r_iter = a13.w;
+		nxw = mysave[14].x;
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -755,7 +828,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					if (!skip) {
 						seeding = true; r_stop = len - PRECALC_LEN;
 						cL = 0; cU = last_row; curT = 1; cursel = 0; s = 0; r = len - 1;
-						nx.buf = lbase + lcap; nx.T = 0;
+						nx.buf = lbase + lcap; nx.T = 0; nxw = 0;
 						mode = LMODE_EXACT;
 					}
 				}
@@ -799,6 +872,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				mysave[11] = make_uint4(lo(h.top.L), hi(h.top.L), lo(h.top.U), hi(h.top.U));
 				mysave[12] = make_uint4(h.top.sa, h.top.runsLo, h.top.runsHi, r_vis_s);
 				mysave[13] = make_uint4(r_vis_a, r_pop, r_push, r_iter);
+				mysave[14] = make_uint4(nxw, 0u, 0u, 0u);
 				n_parked++;
 			}
 			parked = active;
@@ -807,7 +881,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		if (__all(done)) break;
 		if (!__any(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
 
-		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false;
+		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
 		P iL = 0, iU = 0;
 		int widx = 0;
 		if (active) { n_iter++; r_iter++; }
@@ -845,12 +919,18 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 #endif
 				h.pop(e); /* heap_pop :594-610: the top of the best bucket, usually straight from its register mirror */
 				e_score = bk;
-				r_pop++;
-				if (e_score > best_score + kp.mm_score) finish = true; /* :309 */
+				is_group = (e.sa & 3u) == (uint32_t)STATE_GROUP;
+				/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the
+				 * group's last child, which happens in the next iteration, once the children are in place */
+				if (!is_group) r_pop++;
+				if (e_score > best_score + kp.mm_score) { finish = true; if (is_group) r_pop++; } /* :309 (the reference pops that child, then stops) */
 				else {
 					from_pop = true;
 					widx = (int)(e.f & 255u);
-					if (widx > 0) {
+					if (is_group) { /* the children are those of the parent's O_alphabet call (:382-383) */
+						h.num_entries++;
+						need_rank = true; iL = e.L; iU = e.U; alpha = kp.multiref != 0;
+					} else if (widx > 0) {
 						need_rank = true; iL = e.L; iU = e.U;
 						/* an entry with no difference left goes to the exact tail (exact counts); any other one is expanded
 						 * with O_alphabet (:345,382) */
@@ -869,7 +949,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 #ifdef BWB_HIST
 		HIST(H_POP, active && mode == LMODE_POP && (from_pop || finish)); HIST(H_POP_GAPPED, from_pop && ((e.f >> 16) != 0)); HIST(H_POP_FROM_MIRROR, from_pop && h_mirror);
 		HIST(H_EXACT_STEP, active && mode == LMODE_EXACT); HIST(H_NEED_RANK, need_rank); HIST(H_ALPHA, need_rank && alpha);
-		HIST(H_EXACT_MULTI, active && mode == LMODE_EXACT && curT > 1);
+		HIST(H_EXACT_MULTI, active && mode == LMODE_EXACT && curT > 1); HIST(H_ALLOC, from_pop && is_group);
 		const P hw_ = (P)(iU - iL + 1);
 		const bool hsame_ = need_rank && ((P)(iL - 1) >> 7) == (iU >> 7) && iL != 0 && iU != last_row;
 		HIST(H_SAME_BKT, hsame_); HIST(H_TWO_BKT, need_rank && !hsame_);
@@ -902,34 +982,38 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
 		}
 		STAMP(2);
-		HISTW(H_WAVE_NREQ_LE16, nreq <= COOP_MAX_REQ ? 1 : 0);
-		if (nreq > COOP_MAX_REQ) {
-			LaneReq<P> ra, rb;
-			n_bkt += wave_fetch_pair<P>(buckets, last_row, need_rank, (P)(iL - 1), iU, ra, rb, stage, lane); /* every lane of the wave loads */
-			STAMP(14);
-			if (need_rank) ne = lane_children<P>(ra, rb, s_base, alpha, kidL, kidU);
-		} else if (nreq > 0) {
-			unsigned long long rm = rmask;
-			for (int base = 0; base < nreq; base += 8) {
-				ne |= coop_children<P>(buckets, last_row, s_base, rmask, rm, base, need_rank, alpha, iL, iU, kids, lane);
-				for (int t = 0; t < 8; t++) rm &= rm - 1;
-			}
-			n_bkt += (uint32_t)nvis; /* the octet path fetches both buckets of a pair (counted in the owner lane) */
-		}
-		if (!kp.multiref && need_rank) {
-			/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with
-			 * alphabet_size 5): move codes 15, 3, 7, 1 to rows 1..4 */
-			const P a0 = kidL[15 * KID_STRIDE], a1 = kidU[15 * KID_STRIDE], g0 = kidL[3 * KID_STRIDE], g1 = kidU[3 * KID_STRIDE];
-			const P c0 = kidL[7 * KID_STRIDE], c1 = kidU[7 * KID_STRIDE], t0 = kidL[1 * KID_STRIDE], t1 = kidU[1 * KID_STRIDE];
-			kidL[1 * KID_STRIDE] = a0; kidU[1 * KID_STRIDE] = a1; kidL[2 * KID_STRIDE] = g0; kidU[2 * KID_STRIDE] = g1;
-			kidL[3 * KID_STRIDE] = c0; kidU[3 * KID_STRIDE] = c1; kidL[4 * KID_STRIDE] = t0; kidU[4 * KID_STRIDE] = t1;
-			ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
-		}
+		HISTW(H_WAVE_NREQ_LE16, nreq <= 16 ? 1 : 0);
+		KidCtx<P> kc;
+		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
+		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
+		STAMP(14);
+		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
+		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
+		if (!kp.multiref) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
+		auto kid = [&](int j, P &L, P &U) { kid_get<P>(kc, sb, kp.multiref ? j : (int)((0x173Fu >> (4 * (j - 1))) & 15u), L, U); };
 		STAMP(3);
 
 		/* ---- C: act on it ---- */
 		bool exact_step = active && (mode == LMODE_EXACT);
-		if (from_pop) {
+		if (from_pop && is_group) {
+			/* ---- a deletion group has reached the top of its bucket: its children take its place ---- */
+			const int n = __popc(ne);
+			const uint32_t st0 = h.reserve(h.cst, n, ovf);
+			if (!ovf && n > 0) {
+				uint4 *p0 = h.chunk_ptr(st0 >> 6) + ((st0 & 63u) + 1) * ESZ;
+				const uint32_t sd = (e.sa & ~3u) | (uint32_t)STATE_D;
+				const uint64_t eruns = ((uint64_t)e.runsHi << 32) | e.runsLo;
+				uint32_t gm = ne;
+				while (gm) {
+					const int j = __ffs((int)gm) - 1;
+					gm &= gm - 1;
+					kid(j, h.top.L, h.top.U);
+					if (gm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, e.f, sd, eruns); /* (the last child is popped next: the register mirror is its only copy) */
+				}
+				h.top.f = e.f; h.top.sa = sd; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi;
+				h.cst = st0 + (uint32_t)n; h.mark(e_score); h.top_valid = true;
+			}
+		} else if (from_pop) {
 			const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
 			const int e_alen = (int)((e.sa >> 2) & 255u);
 			const int diff_left = max_diff - e_mm - e_go - e_ge;
@@ -955,7 +1039,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					else add_aln(e.L, e.U, e_score, e_alen);
 				} else if (diff_left == 0) { /* exact tail :345-375: its first step uses the children just computed */
 					cL = e.L; cU = e.U; curT = 1; cursel = 0; s = 0; r = e_i - 1;
-					nx.buf = lbase + lcap; nx.T = 0;
+					nx.buf = lbase + lcap; nx.T = 0; nxw = 0;
 					mode = LMODE_EXACT;
 					exact_step = true;
 				} else {
@@ -985,16 +1069,18 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					const bool mm_ok = allow_diff && allow_mm;
 					const uint32_t mem = cr > 3 ? 0u : (kp.multiref ? member_mask(cr) : 2u << cr);
 					/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
-					const uint32_t gapm = (ins_ok ? 1u : 0u) | (del_ok ? ne : 0u);
+					const uint32_t delm = del_ok ? ne : 0u;
 					const uint32_t mgrp = mm_ok ? ne : (ne & mem);
 					const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
-					const int nG = __popc(gapm), nX = __popc(mism), n0 = __popc(matchm);
-					r_push += nG + nX + n0;
+					const int nDel = __popc(delm), nIns = ins_ok ? 1 : 0, nX = __popc(mism), n0 = __popc(matchm);
+					const int nGc = nIns + nDel;            /* gap entries the reference pushes: what is counted */
+					const int nG = nIns + (nDel ? 1 : 0);   /* gap entries stored: the deletions as one group (STATE_GROUP) */
+					r_push += nGc + nX + n0;
 #ifdef BWB_HIST
 					{ const int nne = __popc(ne);
 					  HIST(H_NE0, nne == 0); HIST(H_NE1, nne == 1); HIST(H_NE2, nne == 2); HIST(H_NE3_4, nne == 3 || nne == 4); HIST(H_NE5_8, nne >= 5 && nne <= 8); HIST(H_NE9, nne >= 9);
 					  HIST(H_DEL_OK, del_ok); HIST(H_MM_OK, mm_ok); HIST(H_INS_OK, ins_ok);
-					  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nG; hl_mis += nX; hl_match += n0; }
+					  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nGc; hl_mis += nX; hl_match += n0; }
 #endif
 					/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
 					const int tX = scX == sc0 ? 0 : 1, tG = scG == sc0 ? 0 : (scG == scX ? tX : 2);
@@ -1025,26 +1111,15 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 						uint4 *p0 = h.chunk_ptr(st0 >> 6) + ((st0 & 63u) + 1) * ESZ;
 						uint4 *p1 = h.chunk_ptr(st1 >> 6) + ((st1 & 63u) + 1) * ESZ;
 						uint4 *p2 = h.chunk_ptr(st2 >> 6) + ((st2 & 63u) + 1) * ESZ;
-						auto emit = [&](uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
-							L = pos_enc<P>(L); U = pos_enc<P>(U);
-							if (WIDE) {
-								p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
-								p[1] = make_uint4(f, sa, (uint32_t)runs, (uint32_t)(runs >> 32));
-							} else p[0] = make_uint4((uint32_t)L, (uint32_t)U, f, LHeap<P, WIDE>::pack_w(L, U, sa, (uint32_t)runs));
-							p += ESZ;
-						};
 						bool top_ok = false; /* does h.top mirror the last entry stored on bucket sc0? */
 						STAMP(11);
-						{ /* gap pushes: insertion (keeps the interval), then deletions in code order */
+						{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
+						   * holds the parent's interval (a single deletion child is stored as itself) */
 							uint4 *pg = tG == 0 ? p0 : (tG == 1 ? p1 : p2);
-							uint32_t gm = gapm;
-							if (gm & 1u) { emit(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i); gm &= ~1u; }
-							const uint32_t fd = f_gap | (uint32_t)(e_i & 255), sd = (uint32_t)STATE_D | (alen1 << 2);
-							while (gm) {
-								const int j = __ffs((int)gm) - 1;
-								gm &= gm - 1;
-								emit(pg, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], fd, sd, gruns_d);
-							}
+							if (nIns) emit_entry<P, WIDE>(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i);
+							const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
+							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit_entry<P, WIDE>(pg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d); }
+							else if (nDel) emit_entry<P, WIDE>(pg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d);
 							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
 						}
 						STAMP(12);
@@ -1055,15 +1130,19 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 							while (xm) {
 								const int j = __ffs((int)xm) - 1;
 								xm &= xm - 1;
-								emit(px, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], f_mis, sm, eruns);
+								P cl, cu;
+								kid(j, cl, cu);
+								emit_entry<P, WIDE>(px, cl, cu, f_mis, sm, eruns);
 							}
 							if (tX == 1) p1 = px; else p0 = px;
 							uint32_t mm = matchm;
 							while (mm) {
 								const int j = __ffs((int)mm) - 1;
 								mm &= mm - 1;
-								h.top.L = kidL[j * KID_STRIDE]; h.top.U = kidU[j * KID_STRIDE];
-								emit(p0, h.top.L, h.top.U, f_match, sm, eruns);
+								kid(j, h.top.L, h.top.U);
+								/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket
+								 * being popped): the register mirror is its only copy, its slot is reserved but never written. */
+								if (mm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, f_match, sm, eruns);
 							}
 							if (matchm) { h.top.f = f_match; h.top.sa = sm; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi; top_ok = true; }
 						} else { /* mm_score == 0: one bucket, interleaved in code order */
@@ -1071,11 +1150,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 							while (am) {
 								const int j = __ffs((int)am) - 1;
 								am &= am - 1;
-								emit(p0, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
+								P cl, cu;
+								kid(j, cl, cu);
+								emit_entry<P, WIDE>(p0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
 							}
 						}
 						STAMP(13);
-						h.num_entries += nG + nX + n0;
+						h.num_entries += nGc + nX + n0;
 						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; }
 						if (k1 > 0) { h.bstate[scX] = st1 + (uint32_t)k1; h.mark(scX); }
 						if (k2 > 0) { h.bstate[scG] = st2 + (uint32_t)k2; h.mark(scG); }
@@ -1092,6 +1173,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		STAMP(4);
 		if (exact_step && need_rank) {
 			bool exact_done = false;
+			uint32_t lastW = 0; /* summed width of the list that the step just completed */
 			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
 			else {
 				if (!seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
@@ -1099,12 +1181,16 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;
-					list_add<P>(nx, kidL[j * KID_STRIDE], kidU[j * KID_STRIDE], lcap, ovf);
+					P cl, cu;
+					kid(j, cl, cu);
+					nxw += (uint32_t)(cu - cl + 1);
+					list_add<P>(nx, cl, cu, lcap, ovf);
 				}
 				s++;
 				if (!ovf && s >= curT) {
 					cursel ^= 1; curT = nx.T; cL = nx.tL; cU = nx.tU;
 					nx.buf = lbase + (cursel ^ 1) * lcap; nx.T = 0; s = 0;
+					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < r_stop) exact_done = true; }
 				}
@@ -1139,21 +1225,26 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 						max_diff = (bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1;
 					}
 					bool brk = false;
-					if (e_score == best_score) {
-						for (int k = 0; k < curT; k++) {
-							P L, U;
-							if (k == curT - 1) { L = cL; U = cU; }
-							else { const Intv<P> v = (lbase + cursel * lcap)[k]; L = v.L; U = v.U; }
-							num_best += (int)(uint32_t)(U - L + 1);
-						}
-					} else if (num_best > kp.max_best) brk = true;
+					/* num_best += the width of every interval of the list (:350-352): adjacent intervals merge without changing the
+					 * sum, so it is the running sum of what the last step added - no pass over the list in memory */
+					if (e_score == best_score) num_best += (int)lastW;
+					else if (num_best > kp.max_best) brk = true;
 					if (brk) finish = true;
 					else {
 						const int alen2 = ((int)((e.sa >> 2) & 255u) + e_i) & 255; /* :365 */
-						for (int k = 0; k < curT && !ovf; k++) {
+						const Intv<P> *lst = lbase + cursel * lcap;
+						int k = 0;
+						if (e_go == 0) { /* no duplicate check (align.c:273-280 applies to gapped entries): four list loads in flight at a time */
+							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)sc.acap; k += 4) {
+								const Intv<P> v0 = lst[k], v1 = lst[k + 1], v2 = lst[k + 2], v3 = lst[k + 3];
+								add_aln(v0.L, v0.U, e_score, alen2); add_aln(v1.L, v1.U, e_score, alen2);
+								add_aln(v2.L, v2.U, e_score, alen2); add_aln(v3.L, v3.U, e_score, alen2);
+							}
+						}
+						for (; k < curT && !ovf; k++) {
 							P L, U;
 							if (k == curT - 1) { L = cL; U = cU; }
-							else { const Intv<P> v = (lbase + cursel * lcap)[k]; L = v.L; U = v.U; }
+							else { const Intv<P> v = lst[k]; L = v.L; U = v.U; }
 							add_aln(L, U, e_score, alen2);
 						}
 					}
@@ -1227,17 +1318,19 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	}
 }
 
-/* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_fetch_pair, one
- * side only) and every lane ranks all 15 codes of its own bucket: the access pattern and the ALU work of a rank visit in
- * kl_search / kl_calc_d without anything else.  Same queries and same checksum as k_rank_bench (octet layout). */
+/* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_gather, L rows
+ * only) and every lane ranks all 15 codes of its own bucket from LDS (block_pops): the access pattern and the ALU work of a rank
+ * visit in kl_search / kl_calc_d without anything else.  Same queries and same checksum as k_rank_bench (octet layout). */
 template <typename P>
 __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uint64_t n, uint64_t seed, unsigned long long *checksum) {
 	__shared__ P s_base[BWB_BASE_ROWS * 16];
-	__shared__ u32x4 s_stage[LANE_BLOCK / 64][2 * 64 * 8];
+	__shared__ u32x4 s_zero[8];
+	__shared__ u32x4 s_stage[LANE_BLOCK / 64][WAVE_STAGE_U4];
+	if (threadIdx.x < 32) ((Lds<uint32_t>)&s_zero[0])[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
 	const uint64_t nl = (uint64_t)gridDim.x * LANE_BLOCK;
 	const int lane = (int)(threadIdx.x & 63u);
-	Lds<u32x4> stage = (Lds<u32x4>)&s_stage[threadIdx.x >> 6][0];
+	Lds<u32x4> stage = (Lds<u32x4>)&s_stage[threadIdx.x >> 6][0], zero_row = (Lds<u32x4>)&s_zero[0];
 	const P last_row = (P)(ix.length - 1);
 	unsigned long long acc = 0;
 	const uint64_t n_round = (n + nl - 1) / nl * nl; /* whole waves iterate together */
@@ -1245,14 +1338,22 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		uint64_t x = q * 0x9E3779B97F4A7C15ull + seed;
 		x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
 		const P pos = (P)(x % (ix.length - 1));
-		LaneReq<P> ra, rb;
-		wave_fetch_pair<P>(ix.buckets, last_row, q < n, pos, pos, ra, rb, stage, lane);
-		if (q < n) {
-			uint32_t pop[16];
-			lane_pops<P>(ra, pop);
-			const P *brow = s_base + ra.row * 16;
+		PairInfo<P> pi;
+		pair_setup<P>(last_row, q < n, pos, pos, lane, pi);
+		wave_gather<P>(ix.buckets, pi, 0, stage, lane);
+		uint32_t rel[16], first = 0;
 #pragma unroll
-			for (int j = 1; j < 16; j++) acc += (unsigned long long)lane_val<P>(ra, brow, pop, j) * ((j & 1) ? 3ull : 1ull);
+		for (int c = 0; c < 16; c++) rel[c] = 0;
+		const bool own = pi.blkL != NONE32;
+		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
+		const int rot = own ? (lane >> 1) & 7 : 0;
+		block_pops(row, rot, 0, pi.offL, rel, first);
+#pragma unroll
+		for (int s = 0; s < 4; s++) { const u32x4 c4 = row[(s + rot) & 7]; rel[4 * s] += c4.x; rel[4 * s + 1] += c4.y; rel[4 * s + 2] += c4.z; rel[4 * s + 3] += c4.w; }
+		if (q < n) {
+			const P *brow = s_base + pi.rowL * 16;
+#pragma unroll
+			for (int j = 1; j < 16; j++) acc += (unsigned long long)(P)(brow[j] + (P)rel[cslot(j)]) * ((j & 1) ? 3ull : 1ull);
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

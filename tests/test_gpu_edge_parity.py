@@ -172,7 +172,7 @@ def test_streamed_results_are_published_before_the_host_reads_them(mid_ctx):
     want = []
     for j in range(nbatch):
         off, alns = ctx.align(p, seqs[j * B:(j + 1) * B], lens[j * B:(j + 1) * B])
-        want.append(bw.aln_bytes(off, alns))
+        want.append((off.tobytes(), alns.tobytes()))  # (raw records: serialising 2 M reads in Python would take minutes)
     ctx.flush()
     ctx.reset_stats()
     got = [None] * nbatch
@@ -181,14 +181,14 @@ def test_streamed_results_are_published_before_the_host_reads_them(mid_ctx):
         slot = j % nslot
         if j >= nslot:
             off, alns = ctx.slot_result(slot)
-            got[j - nslot] = bw.aln_bytes(off, alns)
+            got[j - nslot] = (off.tobytes(), alns.tobytes())
         ctx.slot_upload(slot, p, seqs[j * B:(j + 1) * B], lens[j * B:(j + 1) * B])
         ctx.slot_submit(slot)
     for j in range(nbatch - nslot, nbatch):
         off, alns = ctx.slot_result(j % nslot)
-        got[j] = bw.aln_bytes(off, alns)
+        got[j] = (off.tobytes(), alns.tobytes())
     ctx.flush()
-    assert [len(g) for g in got] == [len(w) for w in want]
+    assert [len(g[1]) for g in got] == [len(w[1]) for w in want]
     assert got == want
     assert ctx.stats().n_parked_reads > 0
 

@@ -15,16 +15,6 @@ export GRAFT_REPO_ROOT=$R
 OUT=$R/gpurun_out/$1; shift
 ARGS=$1; shift
 mkdir -p "$OUT"
-show='
-import sys, json
-name = sys.argv[1]
-line = [l for l in sys.stdin.read().splitlines() if l.startswith("{\"metric\"")]
-if not line:
-    print(f"{name:14s} NO BENCH LINE"); sys.exit(0)
-j = json.loads(line[-1]); r = j["roofline"]; k = r["kernels"]
-s, d = k["kl_search"], k["kl_calc_d"]
-print(f"{name:14s} value {j[\"value\"]:10.1f} ms/step {j[\"ms_per_step\"]:9.1f} | search ms/launch {s[\"ms_per_launch\"]:9.1f} x{s[\"launches\"]} dev_frac {s[\"device_frac\"]:.4f} alg192 {s[\"algorithmic_GBs\"]:7.1f} GB/s"
-      f" | calc_d ms {d[\"ms_per_launch\"]:8.1f} dev_frac {d[\"device_frac\"]:.4f} | lanes {r[\"lanes_busy_of_64\"]} rerun {j[\"rerun_reads\"]}")'
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   name=${v%%:*}; rest=${v#*:}; [ "$rest" = "$v" ] && rest=""
@@ -35,7 +25,7 @@ for v in "$@"; do
     for kv in ${envs//,/ }; do export "$kv"; done
     timeout ${AB_TIMEOUT:-1800} python3 $R/bench.py $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err"
   )
-  python3 -c "$show" "$name" < "$OUT/$name.json" | tee -a "$OUT/summary.txt"
+  python3 $R/tools/ab_show.py "$name" < "$OUT/$name.json" | tee -a "$OUT/summary.txt"
   grep -h "bwb hist" "$OUT/$name.err" | tail -1 > "$OUT/$name.hist" 2>/dev/null; [ -s "$OUT/$name.hist" ] || rm -f "$OUT/$name.hist"
   grep -h "stamps" "$OUT/$name.err" | tail -1 >> "$OUT/summary.txt"
 done
