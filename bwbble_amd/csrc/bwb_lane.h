@@ -297,15 +297,16 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 
 /* ---- SA-interval list being built: add_sa_interval (align.c:93-110), tail in registers ------------ */
 template <typename P> struct ListW {
-	Intv<P> *buf;
+	int sel;      /* which of the lane's two lists is being built (the buffer is base + sel * cap: no pointer kept in registers) */
 	int T;        /* intervals so far, including the open tail */
 	P tL, tU;
 };
-template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, P L, P U, int cap, bool &ovf) {
+template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, P L, P U, int cap, bool &ovf) {
 	if (l.T != 0 && L == (P)(l.tU + 1)) { l.tU = U; return; }
 	if (l.T != 0) {
 		if (l.T - 1 >= cap) { ovf = true; return; }
-		l.buf[l.T - 1].L = l.tL; l.buf[l.T - 1].U = l.tU;
+		Intv<P> *buf = base + l.sel * cap;
+		buf[l.T - 1].L = l.tL; buf[l.T - 1].U = l.tU;
 	}
 	l.tL = L; l.tU = U; l.T++;
 }
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 	uint32_t rid = 0;
 	int len = 0, phase = 0, plen = 0, r = 0, z = 0, s = 0, curT = 0, cursel = 0;
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
-	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
+	ListW<P> nx; nx.sel = 0; nx.T = 0; nx.tL = nx.tU = 0;
 	int32_t nm = 0, prev_nm = 0;
 	uint32_t prev_byte = 0, cntN = 0;
 	unsigned long long vis = 0;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 				seq = b.reads + (size_t)rid * b.stride;
 				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
 				cL = 0; cU = last_row; curT = 1;
-				nx.buf = lbase + cap; nx.T = 0;
+				nx.sel = 1; nx.T = 0;
 				active = len > 0;
 				if (!(kp.seed_length && len > kp.seed_length)) {
 					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 				P L, U;
 				kid_get<P>(kc, sb, j, L, U);
 				nm += (int32_t)(uint32_t)(U - L + 1);
-				list_add<P>(nx, L, U, cap, ovf);
+				list_add<P>(nx, lbase, L, U, cap, ovf);
 			}
 			s++;
 		}
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 			/* position finished: swap lists (inexact_match.c:234-237) */
 			cursel ^= 1;
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
-			nx.buf = lbase + (cursel ^ 1) * cap; nx.T = 0; s = 0;
+			nx.sel = cursel ^ 1; nx.T = 0; s = 0;
 			if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
 				cL = 0; cU = last_row; curT = 1; z++;
 				nm = (int32_t)(uint32_t)ix.length;
@@ -698,9 +699,14 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	}
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
+	/* The lane's scratch areas are addressed from its slot number where they are used: `slotv` is passed through an empty asm
+	 * statement in every iteration, so the compiler cannot keep six 64-bit pointers alive across the loop (registers are what
+	 * decides whether three waves fit a SIMD). */
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
-	Intv<P> *lbase = (Intv<P> *)sc.lists + (size_t)slot * 2 * sc.lcap;
-	uint4 *myalns = sc.alns + (size_t)slot * sc.acap * 2;
+	uint32_t slotv = slot;
+#define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
+#define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
+#define mysave (sc.save + (size_t)slotv * SAVE_U4)
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	const uint32_t region = blockIdx.x % sc.n_regions;
 	h.pbase = ((blockIdx.x / sc.n_regions) * LANE_BLOCK + threadIdx.x) * sc.keep;
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
-	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slot * BSTATE_ROW; h.nslots = sc.nslots;
+	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW; h.nslots = sc.nslots;
 	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
 
@@ -725,15 +731,14 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	uint32_t nxw = 0;                                       /* exact tail: summed width of the intervals added to the next list so far (wrapping, like the
 	                                                           reference's int num_best sum :350-352) */
 	P cL = 0, cU = 0;
-	ListW<P> nx; nx.buf = lbase; nx.T = 0; nx.tL = nx.tU = 0;
+	ListW<P> nx; nx.sel = 0; nx.T = 0; nx.tL = nx.tU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 	int e_score = 0;
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
-	unsigned long long vis_s = 0, vis_a = 0, n_pop = 0, n_push = 0, n_aln_tot = 0;
-	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed only when the read completes */
-	unsigned long long n_iter = 0, w_iter = 0;
-	uint32_t r_iter = 0, n_bkt = 0, n_parked = 0;
+	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
+	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
+	uint32_t r_iter = 0, n_bkt = 0;
 	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -742,7 +747,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	unsigned long long hist[H_N] = { 0 };
 	unsigned long long hl_gap = 0, hl_mis = 0, hl_match = 0; /* per-lane sums */
 #endif
-	uint4 *const mysave = sc.save + (size_t)slot * SAVE_U4;
 	if (wk.resume && (mysave[0].x & 1u)) {
 		/* ---- resume the read this lane parked at the end of the previous slice ---- */
 		const uint4 a0 = mysave[0], a1 = mysave[1], a2 = mysave[2], a3 = mysave[3], a4 = mysave[4], a5 = mysave[5], a6 = mysave[6],
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		const uint32_t fl = a0.x;
 		mode = (fl >> 1) & 1u; cursel = (fl >> 2) & 1u; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
 		myslot = (fl >> 8) & 0xFFu;
-		nx.buf = lbase + ((fl >> 6) & 1u) * lcap;
+		nx.sel = (int)((fl >> 6) & 1u);
 		rid = a0.y;
 		len = (int)(a0.z & 255u); best_score = (int)((a0.z >> 8) & 255u); max_diff = (int)((a0.z >> 16) & 255u); e_score = (int)(a0.z >> 24);
 		num_best = (int)a0.w;
@@ -778,6 +782,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 
 	for (;;) {
 		STAMP(7);
+		asm volatile("" : "+v"(slotv));
+		h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW;
 		bool admit = !active && !done;
 		if (admit) {
 			/* admission: what a read will need is not known in advance, and a read that finds the pool empty is given up and
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					if (!skip) {
 						seeding = true; r_stop = len - PRECALC_LEN;
 						cL = 0; cU = last_row; curT = 1; cursel = 0; s = 0; r = len - 1;
-						nx.buf = lbase + lcap; nx.T = 0; nxw = 0;
+						nx.sel = 1; nx.T = 0; nxw = 0;
 						mode = LMODE_EXACT;
 					}
 				}
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				auto lo = [](P v) { return (uint32_t)v; };
 				auto hi = [](P v) { return (uint32_t)((uint64_t)v >> 32); };
 				const uint32_t fl = 1u | ((uint32_t)mode << 1) | ((uint32_t)cursel << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
-				                    ((h.top_valid ? 1u : 0u) << 5) | ((nx.buf != lbase ? 1u : 0u) << 6) | (myslot << 8);
+				                    ((h.top_valid ? 1u : 0u) << 5) | ((uint32_t)nx.sel << 6) | (myslot << 8);
 				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)best_score << 8) | ((uint32_t)max_diff << 16) | ((uint32_t)e_score << 24), (uint32_t)num_best);
 				mysave[1] = make_uint4((uint32_t)n_alns, (uint32_t)r, (uint32_t)s, (uint32_t)curT);
 				mysave[2] = make_uint4((uint32_t)r_stop, (uint32_t)nx.T, lo(cL), hi(cL));
@@ -873,7 +879,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				mysave[12] = make_uint4(h.top.sa, h.top.runsLo, h.top.runsHi, r_vis_s);
 				mysave[13] = make_uint4(r_vis_a, r_pop, r_push, r_iter);
 				mysave[14] = make_uint4(nxw, 0u, 0u, 0u);
-				n_parked++;
 			}
 			parked = active;
 			break;
@@ -987,6 +992,8 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		STAMP(14);
+		asm volatile("" : "+v"(slotv));
+		h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW;
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
 		if (!kp.multiref) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
@@ -1039,7 +1046,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					else add_aln(e.L, e.U, e_score, e_alen);
 				} else if (diff_left == 0) { /* exact tail :345-375: its first step uses the children just computed */
 					cL = e.L; cU = e.U; curT = 1; cursel = 0; s = 0; r = e_i - 1;
-					nx.buf = lbase + lcap; nx.T = 0; nxw = 0;
+					nx.sel = 1; nx.T = 0; nxw = 0;
 					mode = LMODE_EXACT;
 					exact_step = true;
 				} else {
@@ -1184,12 +1191,12 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 					P cl, cu;
 					kid(j, cl, cu);
 					nxw += (uint32_t)(cu - cl + 1);
-					list_add<P>(nx, cl, cu, lcap, ovf);
+					list_add<P>(nx, lbase, cl, cu, lcap, ovf);
 				}
 				s++;
 				if (!ovf && s >= curT) {
 					cursel ^= 1; curT = nx.T; cL = nx.tL; cU = nx.tU;
-					nx.buf = lbase + (cursel ^ 1) * lcap; nx.T = 0; s = 0;
+					nx.sel = cursel ^ 1; nx.T = 0; s = 0;
 					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < r_stop) exact_done = true; }
@@ -1275,7 +1282,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			out.n[rid] = (ovf || outovf) ? 0u : (uint32_t)n_alns;
 			d.b.status[rid] = ovf ? ST_SCRATCH_OVF : (outovf ? ST_OUT_OVF : ST_OK);
 			if (d.b.dbg_iters) d.b.dbg_iters[rid] = r_iter;
-			if (!ovf && !outovf) { n_aln_tot += n_alns; vis_s += r_vis_s; vis_a += r_vis_a; n_pop += r_pop; n_push += r_push; }
+			if (!ovf && !outovf) { /* (a read finishes once in tens of thousands of iterations: five atomics instead of ten registers held across the loop) */
+				if (n_alns) atomicAdd(&stats[STAT_ALNS], (unsigned long long)n_alns);
+				if (r_vis_s) atomicAdd(&stats[STAT_VIS_SINGLE], (unsigned long long)r_vis_s);
+				if (r_vis_a) atomicAdd(&stats[STAT_VIS_ALPHA], (unsigned long long)r_vis_a);
+				atomicAdd(&stats[STAT_POPS], (unsigned long long)r_pop);
+				atomicAdd(&stats[STAT_PUSHES], (unsigned long long)r_push);
+			}
 			publish_done(d.done);
 			/* leave every bucket state empty for the next read and give its chunks back */
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_sum, (h.pused + h.xcnt + 15u) >> 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1287,16 +1300,11 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			active = false;
 		}
 	}
-	if (vis_s) atomicAdd(&stats[STAT_VIS_SINGLE], vis_s);
-	if (vis_a) atomicAdd(&stats[STAT_VIS_ALPHA], vis_a);
-	if (n_pop) atomicAdd(&stats[STAT_POPS], n_pop);
-	if (n_push) atomicAdd(&stats[STAT_PUSHES], n_push);
-	if (n_aln_tot) atomicAdd(&stats[STAT_ALNS], n_aln_tot);
 	if (n_bkt) atomicAdd(&stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
-	if (n_parked) atomicAdd(&stats[STAT_PARKED], (unsigned long long)n_parked);
-	atomicAdd(&stats[STAT_N], n_iter);        /* debug: total loop iterations */
-	atomicMax(&stats[STAT_N_MAX], n_iter);    /* debug: longest lane */
-	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[STAT_WAVE_ITERS], w_iter); /* debug: wave iterations */
+	if (parked) atomicAdd(&stats[STAT_PARKED], 1ull);
+	atomicAdd(&stats[STAT_N], (unsigned long long)n_iter);        /* total loop iterations */
+	atomicMax(&stats[STAT_N_MAX], (unsigned long long)n_iter);    /* longest lane */
+	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[STAT_WAVE_ITERS], (unsigned long long)w_iter); /* wave iterations */
 #ifdef BWB_STAMPS
 	if (n_iter) for (int k = 0; k < 16; k++) atomicAdd(&stats[STAT_STAMPS + k], seg[k]);
 #endif
@@ -1317,6 +1325,10 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		bs[0] = (uint32_t)v; bs[1] = (uint32_t)(v >> 32); bs[2] = __hip_atomic_load((Lds<unsigned int>)&s_nfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 }
+
+#undef lbase
+#undef myalns
+#undef mysave
 
 /* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_gather, L rows
  * only) and every lane ranks all 15 codes of its own bucket from LDS (block_pops): the access pattern and the ALU work of a rank
