@@ -161,10 +161,11 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	__builtin_amdgcn_wave_barrier();
 }
 
-/* acc[j] += #j among the characters [lo, hi] of the block whose planes are in `row` (slices 4-7, slice k at row[(k + rot) & 7]),
- * j = 1..15; acc[] is in the order of a bucket's count slices: acc[4 s + t] <-> code {2s, 2s+1, 2s+8, 2s+9}[t].
+/* acc[] += #j among the characters [lo, hi] of the block whose planes are in `row` (slices 4-7, slice k at row[(k + rot) & 7]) for
+ * the eight codes j = 8 HALF .. 8 HALF + 7; acc[2 s + t] <-> code 8 HALF + 2 s + t, which is component 2 HALF + t of count slice s.
  * `first` = code of the block's first character (bwt.c:780).  One sub-block at a time: 4 plane words live. */
-__device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[16], uint32_t &first) {
+template <int HALF>
+__device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[8], uint32_t &first) {
 #pragma unroll
 	for (int w = 0; w < 4; w++) {
 		const u32x4 p = row[(4 + w + rot) & 7];
@@ -172,15 +173,11 @@ __device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int 
 		const int nh = hi + 1 - 32 * w, nl = lo - 32 * w; /* characters [0, nh) minus [0, nl) of this sub-block */
 		const uint32_t mh = nh <= 0 ? 0u : (nh >= 32 ? 0xFFFFFFFFu : ((1u << nh) - 1u));
 		const uint32_t ml = nl <= 0 ? 0u : (nl >= 32 ? 0xFFFFFFFFu : ((1u << nl) - 1u));
-		const uint32_t m = mh & ~ml;
+		const uint32_t m = mh & ~ml & (HALF ? p.w : ~p.w);   /* bit 3 of the code */
 		const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
-		const uint32_t m2 = m & ~p.z, m2p = m & p.z;
-		const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
+		const uint32_t b[2] = { m & ~p.z, m & p.z };
 #pragma unroll
-		for (int c = 1; c < 16; c++) {
-			const int s = (c & 7) >> 1, t = (c & 1) + 2 * (c >> 3);
-			acc[4 * s + t] += __popc(a[c & 3] & b[c >> 2]);
-		}
+		for (int c = 0; c < 8; c++) acc[c] += __popc(a[c & 3] & b[c >> 2]);
 		__builtin_amdgcn_sched_barrier(0); /* (keeps the four sub-blocks apart: interleaved they need 4 x the registers) */
 	}
 }
@@ -226,18 +223,20 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
 	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
-	uint32_t acc[16];
 	{ /* side L: relL = counts + #j in [0, offL] -> slices 0-3 of the own row */
-#pragma unroll
-		for (int c = 0; c < 16; c++) acc[c] = 0;
-		uint32_t fL = 0;
 		const bool have = pi.blkL != NONE32;
-		block_pops(have ? own : zero_row, have ? rot : 0, 0, pi.offL, acc, fL);
+		const Lds<u32x4> src = have ? own : zero_row;
+		const int srot = have ? rot : 0;
+		uint32_t fL = 0, a0[8], a1[8];
+#pragma unroll
+		for (int c = 0; c < 8; c++) a0[c] = a1[c] = 0;
+		block_pops<0>(src, srot, 0, pi.offL, a0, fL);
+		block_pops<1>(src, srot, 0, pi.offL, a1, fL);
 #pragma unroll
 		for (int s = 0; s < 4; s++) {
-			u32x4 q = (have ? own : zero_row)[(s + (have ? rot : 0)) & 7];
-			q.x += acc[4 * s]; q.y += acc[4 * s + 1]; q.z += acc[4 * s + 2]; q.w += acc[4 * s + 3];
-			if (kc.qL) { /* (codes 5, 9, 11, 13 are slots {2,1}, {0,3}, {1,3}, {2,3}) */
+			u32x4 q = src[(s + srot) & 7];
+			q.x += a0[2 * s]; q.y += a0[2 * s + 1]; q.z += a1[2 * s]; q.w += a1[2 * s + 1];
+			if (kc.qL) { /* (codes 5, 9, 11, 13 are components {2,y}, {0,w}, {1,w}, {2,w}) */
 				if (s == 2) q.y = fL == 5u ? 0u : 1u;
 				if (s == 0) q.w = fL == 9u ? 0u : 1u;
 				if (s == 1) q.w = fL == 11u ? 0u : 1u;
@@ -258,28 +257,25 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 			const uint32_t k = pi.ku - (uint32_t)first;
 			const Lds<u32x4> src = fetched ? stage + 512 + k * 8 : (pi.same ? own : zero_row);
 			const int srot = fetched ? (int)((k >> 1) & 7) : (pi.same ? rot : 0);
+			const int lo = pi.same ? pi.offL + 1 : 0;
+			uint32_t fU = 0, a0[8], a1[8];
 #pragma unroll
-			for (int c = 0; c < 16; c++) acc[c] = 0;
-			uint32_t fU = 0;
-			block_pops(src, srot, pi.same ? pi.offL + 1 : 0, pi.offU, acc, fU);
+			for (int c = 0; c < 8; c++) a0[c] = a1[c] = 0;
+			block_pops<0>(src, srot, lo, pi.offU, a0, fU);
+			block_pops<1>(src, srot, lo, pi.offU, a1, fU); /* (the own row's planes are read before relU overwrites them) */
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
 				u32x4 q = src[(s + srot) & 7];          /* same bucket: relL (written above); else the U bucket's counts */
 				const u32x4 l = own[(s + rot) & 7];      /* relL */
-				q.x += acc[4 * s]; q.y += acc[4 * s + 1]; q.z += acc[4 * s + 2]; q.w += acc[4 * s + 3];
+				q.x += a0[2 * s]; q.y += a0[2 * s + 1]; q.z += a1[2 * s]; q.w += a1[2 * s + 1];
 				if (kc.qU) {
 					if (s == 2) q.y = fU == 5u ? 0u : 1u;
 					if (s == 0) q.w = fU == 9u ? 0u : 1u;
 					if (s == 1) q.w = fU == 11u ? 0u : 1u;
 					if (s == 2) q.w = fU == 13u ? 0u : 1u;
 				}
-				/* non-empty children, when both positions have the same base row: relU > relL (slot t of slice s is code {2s, 2s+1, 2s+8, 2s+9}[t]) */
+				/* non-empty children, when both positions have the same base row: relU > relL (component t of slice s is code {2s, 2s+1, 2s+8, 2s+9}[t]) */
 				ne |= (q.x > l.x ? 1u : 0u) << (2 * s) | (q.y > l.y ? 1u : 0u) << (2 * s + 1) | (q.z > l.z ? 1u : 0u) << (2 * s + 8) | (q.w > l.w ? 1u : 0u) << (2 * s + 9);
-				acc[4 * s] = q.x; acc[4 * s + 1] = q.y; acc[4 * s + 2] = q.z; acc[4 * s + 3] = q.w;
-			}
-#pragma unroll
-			for (int s = 0; s < 4; s++) { /* (after every read of the own row's planes) */
-				u32x4 q; q.x = acc[4 * s]; q.y = acc[4 * s + 1]; q.z = acc[4 * s + 2]; q.w = acc[4 * s + 3];
 				own[(4 + s + rot) & 7] = q;
 			}
 		}
@@ -289,6 +285,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	if (__any(rows_differ)) { /* a pair that straddles a superblock boundary or has a special position (the root's -1 / length-1): compare positions */
 		if (rows_differ) {
 			ne = 0;
+#pragma unroll 1
 			for (int j = 1; j < 16; j++) { P L, U; kid_get<P>(kc, s_base, j, L, U); ne |= (L <= U ? 1u : 0u) << j; }
 		}
 	}
@@ -1359,13 +1356,14 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		const bool own = pi.blkL != NONE32;
 		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
 		const int rot = own ? (lane >> 1) & 7 : 0;
-		block_pops(row, rot, 0, pi.offL, rel, first);
+		block_pops<0>(row, rot, 0, pi.offL, rel, first);
+		block_pops<1>(row, rot, 0, pi.offL, rel + 8, first);
 #pragma unroll
-		for (int s = 0; s < 4; s++) { const u32x4 c4 = row[(s + rot) & 7]; rel[4 * s] += c4.x; rel[4 * s + 1] += c4.y; rel[4 * s + 2] += c4.z; rel[4 * s + 3] += c4.w; }
+		for (int s = 0; s < 4; s++) { const u32x4 c4 = row[(s + rot) & 7]; rel[2 * s] += c4.x; rel[2 * s + 1] += c4.y; rel[8 + 2 * s] += c4.z; rel[8 + 2 * s + 1] += c4.w; }
 		if (q < n) {
 			const P *brow = s_base + pi.rowL * 16;
 #pragma unroll
-			for (int j = 1; j < 16; j++) acc += (unsigned long long)(P)(brow[j] + (P)rel[cslot(j)]) * ((j & 1) ? 3ull : 1ull);
+			for (int j = 1; j < 16; j++) acc += (unsigned long long)(P)(brow[j] + (P)rel[j]) * ((j & 1) ? 3ull : 1ull);
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
