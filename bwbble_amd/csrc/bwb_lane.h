@@ -770,6 +770,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		h.top.sa = a12.x; h.top.runsLo = a12.y; h.top.runsHi = a12.z; r_vis_s = a12.w;
 		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z; r_iter = a13.w;
 		nxw = mysave[14].x;
+		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -965,10 +966,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
 		uint32_t wd = 0, ws = 0, ne = 0;
 		int cr = 4, nvis = 0;
-		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504) */
-		const int e_state = (int)(e.sa & 3u);
-		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
-		uint32_t stX = NONE32, stG = NONE32;
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
 		if (need_rank || (from_pop && len < kp.seed_length)) { /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
@@ -976,10 +973,6 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
 			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
-			if (from_pop) { /* (clamped: an entry near the top score is never expanded, but the prefetch is unconditional) */
-				stX = h.bstate[scX < nb ? scX : nb - 1];
-				stG = h.bstate[scG < nb ? scG : nb - 1];
-			}
 			const P pl = (P)(iL - 1);
 			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
 		}
@@ -991,6 +984,15 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		STAMP(14);
 		asm volatile("" : "+v"(slotv));
 		h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW;
+		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504) */
+		const int e_state = (int)(e.sa & 3u);
+		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
+		uint32_t stX = NONE32, stG = NONE32;
+		if (from_pop) { /* the side heap buckets' states, on their way while the entry is examined (clamped: an entry near the top score is
+		                   never expanded, but the load is unconditional).  Issued after the rank: two registers less across it. */
+			stX = h.bstate[scX < nb ? scX : nb - 1];
+			stG = h.bstate[scG < nb ? scG : nb - 1];
+		}
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
 		if (!kp.multiref) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
