@@ -127,7 +127,7 @@ struct bwb_hip_ctx {
 	ScratchClass cls[3];
 	DevMem d_pool, d_pool_bump;         /* heap chunk pool, POOL_REGIONS equal regions (the re-run classes use it after a drain); bump counters (two sets) */
 	uint32_t keep = 256;                /* chunks of a lane's private run (BWB_KEEP) */
-	int bpc_search = 2, bpc_calcd = 2;
+	int bpc_search = LANE_WAVES_PER_SIMD, bpc_calcd = LANE_WAVES_PER_SIMD; /* blocks of four waves per CU = waves per SIMD */
 	bool wide = false;                  /* 32-byte heap entries (max_gapo > 1: more than one gap run per path) */
 	bool parked = false;                /* reads may be parked in the class-0 save area (the last class-0 launch was a non-draining slice) */
 	uint64_t n_launches = 0;            /* class-0 search launches so far */
@@ -282,7 +282,7 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
 	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
-	const size_t lanes = std::min<size_t>(max_reads_resident(c), (size_t)c->num_cu * 2 * LANE_BLOCK);
+	const size_t lanes = std::min<size_t>(max_reads_resident(c), (size_t)c->num_cu * (size_t)c->bpc_search * LANE_BLOCK);
 	const size_t index_mb = (size_t)(c->ix.nblk >> 13) + 1;
 	const size_t per_lane = ((size_t)c->keep << 10) + std::min<size_t>((size_t)1536 << 10, index_mb << 9);
 	size_t want = std::max<size_t>((size_t)1 << 30, lanes * per_lane / 4 * 5 * (c->wide ? 2 : 1));
@@ -303,9 +303,9 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	ScratchClass &s = c->cls[k];
 	uint32_t blocks, lcap, acap;
 	if (k == 0) {
-		/* 2 blocks (8 waves) per CU for both kernels (a third kl_calc_d block per CU measured no faster) */
+		/* 3 blocks (12 waves) per CU for both kernels: what their register and LDS budgets are built for (bwb_lane.h) */
 		if (!s.ready) {
-			c->bpc_search = 2; c->bpc_calcd = 2;
+			c->bpc_search = LANE_WAVES_PER_SIMD; c->bpc_calcd = LANE_WAVES_PER_SIMD;
 			if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
 			if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
 			if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
@@ -379,6 +379,7 @@ static int check_params(const bwb_params *p, int *nb_out) {
 	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
 	if (p->seed_length < 0 || p->seed_length > 255) return fail(BWB_E_ARG, "seed_length must be in [0,255]");
 	if (p->mm_score < 0 || p->gapo_score < 0 || p->gape_score < 0) return fail(BWB_E_ARG, "negative penalties are not supported");
+	if (p->mm_score > 63 || p->gapo_score > 63 || p->gape_score > 63) return fail(BWB_E_ARG, "penalties (-M, -O, -E) above 63 are not supported on the GPU path");
 	const int nb = (p->max_diff + 1) * p->mm_score + (p->max_gapo + 1) * p->gapo_score + (p->max_gape + 1) * p->gape_score; /* heap_init :513 */
 	if (nb < 1 || nb > 128) return fail(BWB_E_ARG, "score range (heap buckets) must be in [1,128]");
 	if (p->max_entries < 1) return fail(BWB_E_ARG, "max_entries must be positive");
@@ -874,8 +875,8 @@ static int read_device_stats(bwb_hip_ctx *c) {
 	}
 #endif
 	if (c->dbg) {
-		fprintf(stderr, "[bwb] search loop iterations: total %llu, longest lane %llu, wave iterations %llu (%.1f of 64 lanes busy), reads parked at slice ends %llu\n",
-		        st[STAT_N], st[STAT_N_MAX], st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS] ? (double)st[STAT_N] / (double)st[STAT_WAVE_ITERS] : 0.0, st[STAT_PARKED]);
+		fprintf(stderr, "[bwb] search loop iterations: total %llu, wave iterations %llu (%.1f of 64 lanes busy), reads parked at slice ends %llu\n",
+		        st[STAT_N], st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS] ? (double)st[STAT_N] / (double)st[STAT_WAVE_ITERS] : 0.0, st[STAT_PARKED]);
 	}
 	return BWB_OK;
 }

@@ -30,6 +30,13 @@
 #include "bwb_kernels.h"
 
 #define LANE_BLOCK 256
+/* Both alignment kernels are built for THREE waves per SIMD (three 256-thread blocks per CU): at most 168 registers per lane and
+ * 52.6 KB of LDS per block.  Round 2 ran two (256 registers, 66 KB): the waves spent half their time waiting on memory with the
+ * SIMDs' issue slots a third used; the third wave is what the round-3 register and LDS diet (rank from LDS, children in relative
+ * form, list selector, window mask of the non-empty buckets, statistics straight to memory) is for. */
+#ifndef LANE_WAVES_PER_SIMD
+#define LANE_WAVES_PER_SIMD 3
+#endif
 /* lane-private LDS columns: explicit LDS address space, so they compile to ds_read/ds_write (a generic or volatile
  * pointer here turns every access into a flat_* instruction with 64-bit addresses and full waits) */
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
@@ -209,14 +216,14 @@ template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &k
  * Which of the two a visit needs is known before the rank: alpha for an expansion (inexact_match.c:382-383), exact for
  * calculate_d / the exact tail.  Gathers (every lane of the wave takes part), ranks both sides from LDS, leaves the children
  * in relative form in the lane's row (kid_get).  Returns the bitmask of non-empty children (bits 1..15); n_bkt += buckets
- * fetched for this lane.
+ * fetched for the WAVE (a wave-uniform counter).
  * Side U of a pair that shares its bucket with side L (five in six) is relL + #j among the characters (L-1, U]: the same planes. */
 template <typename P>
 __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buckets, P last_row, bool need, P iL, P iU, bool alpha, Lds<P> s_base,
                                                   Lds<u32x4> stage, Lds<u32x4> zero_row, int lane, uint32_t &n_bkt, KidCtx<P> &kc) {
 	PairInfo<P> pi;
 	pair_setup<P>(last_row, need, (P)(iL - 1), iU, lane, pi);
-	n_bkt += (pi.blkL != NONE32 ? 1u : 0u) + (pi.blkU != NONE32 ? 1u : 0u);
+	n_bkt += (uint32_t)__popcll(__ballot(pi.blkL != NONE32)) + (uint32_t)pi.nU; /* (wave-uniform: the whole wave's buckets, added up by lane 0 at the end) */
 	wave_gather<P>(buckets, pi, 0, stage, lane);
 	const Lds<u32x4> own = stage + lane * 8;
 	const int rot = (lane >> 1) & 7;
@@ -327,7 +334,7 @@ __device__ __forceinline__ uint32_t grab_read(const Work &wk) {
  * k_calc_d (one read per lane)
  * ========================================================================================== */
 template <typename P>
-__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b, Work wk, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
+__global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(DevIndex ix, Batch b, Work wk, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
                                                         uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_calc_d(DevIndex ix, Batch b,
 		}
 	}
 	if (vis) { atomicAdd(&stats[STAT_VIS_SINGLE], vis); atomicAdd(&stats[STAT_VIS_CALCD], vis); }
-	if (n_bkt) atomicAdd(&stats[STAT_BKT_CALCD], (unsigned long long)n_bkt);
+	if (lane == 0 && n_bkt) atomicAdd(&stats[STAT_BKT_CALCD], (unsigned long long)n_bkt);
 }
 
 /* ============================================================================================
@@ -491,14 +498,16 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t pool_cap;
 	uint32_t *bstate;      /* this lane's row: bstate[s] */
 	uint32_t nslots;
-	uint32_t fhead, fnext; /* chunks emptied by pops during this read (LIFO through header .x) and the link of its head */
+	uint32_t fhead;        /* chunks emptied by pops during this read (LIFO through header .x) */
 	uint32_t pbase, pused, keep; /* the lane's private run of `keep` consecutive chunks and how many of them this read has taken */
 	uint32_t pshared;            /* first chunk of the region's shared part (after every lane's private run) */
 	uint32_t xhead, xtail;       /* chunks the current read took beyond the private chain */
 	Lds<unsigned long long> blockfree; /* head of this block's stack of recycled chunks (LDS): version<<32 | chunk */
 	Lds<unsigned int> nfree;     /* chunks on that stack */
 	uint32_t xcnt;               /* chunks on the excess chain */
-	uint64_t neLo, neHi;   /* non-empty buckets */
+	uint64_t neW;          /* non-empty buckets, as a window above the cached one: bit k = bucket cb + k.  Entries are popped in
+	                          non-decreasing score order and a child's score exceeds its parent's by at most one penalty, so every
+	                          non-empty bucket lies in [cb, cb + 63] (penalties above 63 are refused, bwb_hip.hip check_params) */
 	int cb;                /* bucket whose state is cached in registers = score of the entry last popped */
 	uint32_t cst;
 	int num_entries;
@@ -513,15 +522,16 @@ template <typename P, bool WIDE> struct LHeap {
 		return w;
 	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { fhead = fnext = NONE32; pused = 0; neLo = neHi = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
-	__device__ __forceinline__ void mark(int s) { if (s < 64) neLo |= 1ull << s; else neHi |= 1ull << (s - 64); }
-	__device__ __forceinline__ void unmark(int s) { if (s < 64) neLo &= ~(1ull << s); else neHi &= ~(1ull << (s - 64)); }
+	__device__ __forceinline__ void reset() { fhead = NONE32; pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; }
+	__device__ __forceinline__ void mark(int s) { neW |= 1ull << (s - cb); }
+	__device__ __forceinline__ void unmark(int s) { neW &= ~(1ull << (s - cb)); }
 	__device__ __forceinline__ int best(int nb) const {
-		return neLo ? __ffsll((long long)neLo) - 1 : (neHi ? 64 + __ffsll((long long)neHi) - 1 : nb);
+		return neW ? cb + __ffsll((long long)neW) - 1 : nb;
 	}
 	__device__ __forceinline__ void switch_cache(int s) {
 		if (s == cb) return;
 		bstate[cb] = cst;
+		neW >>= (s - cb); /* (s > cb: the cached bucket is empty and nothing lies below it) */
 		cb = s; cst = bstate[s];
 		top_valid = false;
 	}
@@ -532,10 +542,9 @@ template <typename P, bool WIDE> struct LHeap {
 	 * excess chain and goes back to the block stack in one push when the read ends, so the pool holds what the reads in
 	 * flight need, not the worst case every lane has ever seen. */
 	__device__ __forceinline__ uint32_t alloc(bool &ovf) {
-		if (fhead != NONE32) { /* the link of the new head is fetched now and needed at the next allocation at the earliest */
+		if (fhead != NONE32) { /* (round 2 fetched the link one allocation ahead: a register across the whole loop for a load that happens once in 63 pushes) */
 			const uint32_t c = fhead;
-			fhead = fnext;
-			fnext = fhead != NONE32 ? chunk_ptr(fhead)[0].x : NONE32;
+			fhead = chunk_ptr(c)[0].x;
 			return c;
 		}
 		if (pused < keep) return pbase + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
@@ -610,7 +619,7 @@ template <typename P, bool WIDE> struct LHeap {
 		if ((cst & 63u) == 1u) {
 			uint4 *p = chunk_ptr(cst >> 6);
 			const uint32_t pv = p[0].y;
-			p[0].x = fhead; fnext = fhead; fhead = cst >> 6; /* chunk goes to the private free list */
+			p[0].x = fhead; fhead = cst >> 6; /* chunk goes to the private free list */
 			cst = pv;
 			if (pv == NONE32) unmark(cb);
 			top_valid = false;
@@ -677,7 +686,7 @@ enum { H_ITER = 0, H_POP, H_POP_FROM_MIRROR, H_POP_GAPPED, H_PRUNED, H_HIT, H_EX
  * scratch anyway - and leaves; the next launch (which starts the next batch) resumes them in the same lanes.  A parked read
  * belongs to an earlier slot than the reads its wave starts next, hence the per-lane `myslot` and the slot table. */
 template <typename P, bool WIDE>
-__global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
+__global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
 	const int lane = (int)(threadIdx.x & 63u);
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
-	uint32_t r_iter = 0, n_bkt = 0;
+	uint32_t n_bkt = 0;
 	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -762,13 +771,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		nx.tU = p64(a4.x, a4.y); nxi.L = p64(a4.z, a4.w);
 		nxi.U = p64(a5.x, a5.y); e.L = p64(a5.z, a5.w);
 		e.U = p64(a6.x, a6.y); e.f = a6.z; e.sa = a6.w;
-		e.runsLo = a7.x; e.runsHi = a7.y; h.fhead = a7.z; h.fnext = a7.w;
+		e.runsLo = a7.x; e.runsHi = a7.y; h.fhead = a7.z;
 		h.pused = a8.x; h.xhead = a8.y; h.xtail = a8.z; h.xcnt = a8.w;
-		h.neLo = ((uint64_t)a9.y << 32) | a9.x; h.neHi = ((uint64_t)a9.w << 32) | a9.z;
+		h.neW = ((uint64_t)a9.y << 32) | a9.x;
 		h.cb = (int)a10.x; h.cst = a10.y; h.num_entries = (int)a10.z; h.top.f = a10.w;
 		h.top.L = p64(a11.x, a11.y); h.top.U = p64(a11.z, a11.w);
 		h.top.sa = a12.x; h.top.runsLo = a12.y; h.top.runsHi = a12.z; r_vis_s = a12.w;
-		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z; r_iter = a13.w;
+		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z;
 		nxw = mysave[14].x;
 		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
@@ -808,7 +817,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				const Batch &b = descs[wk.slot].b;
 				myslot = wk.slot;
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				r_vis_s = r_vis_a = r_pop = r_push = 0; r_iter = 0;
+				r_vis_s = r_vis_a = r_pop = r_push = 0;
 				len = b.lens[rid];
 				const bool unrep = len == BAD_LEN;
 				if (unrep) len = 0;
@@ -869,13 +878,13 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 				mysave[4] = make_uint4(lo(nx.tU), hi(nx.tU), lo(nxi.L), hi(nxi.L));
 				mysave[5] = make_uint4(lo(nxi.U), hi(nxi.U), lo(e.L), hi(e.L));
 				mysave[6] = make_uint4(lo(e.U), hi(e.U), e.f, e.sa);
-				mysave[7] = make_uint4(e.runsLo, e.runsHi, h.fhead, h.fnext);
+				mysave[7] = make_uint4(e.runsLo, e.runsHi, h.fhead, 0u);
 				mysave[8] = make_uint4(h.pused, h.xhead, h.xtail, h.xcnt);
-				mysave[9] = make_uint4((uint32_t)h.neLo, (uint32_t)(h.neLo >> 32), (uint32_t)h.neHi, (uint32_t)(h.neHi >> 32));
+				mysave[9] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), 0u, 0u);
 				mysave[10] = make_uint4((uint32_t)h.cb, h.cst, (uint32_t)h.num_entries, h.top.f);
 				mysave[11] = make_uint4(lo(h.top.L), hi(h.top.L), lo(h.top.U), hi(h.top.U));
 				mysave[12] = make_uint4(h.top.sa, h.top.runsLo, h.top.runsHi, r_vis_s);
-				mysave[13] = make_uint4(r_vis_a, r_pop, r_push, r_iter);
+				mysave[13] = make_uint4(r_vis_a, r_pop, r_push, 0u);
 				mysave[14] = make_uint4(nxw, 0u, 0u, 0u);
 			}
 			parked = active;
@@ -887,7 +896,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
 		P iL = 0, iU = 0;
 		int widx = 0;
-		if (active) { n_iter++; r_iter++; }
+		n_iter += (uint32_t)__popcll(__ballot(active)); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
 		w_iter++;
 		HIST(H_ITER, active); HISTW(H_WAVE_ITERS, 1);
 #ifdef BWB_HIST
@@ -1280,7 +1289,7 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			out.off[rid] = off;
 			out.n[rid] = (ovf || outovf) ? 0u : (uint32_t)n_alns;
 			d.b.status[rid] = ovf ? ST_SCRATCH_OVF : (outovf ? ST_OUT_OVF : ST_OK);
-			if (d.b.dbg_iters) d.b.dbg_iters[rid] = r_iter;
+			if (d.b.dbg_iters) d.b.dbg_iters[rid] = r_pop + r_vis_s / 2; /* (developer aid: about the loop iterations the read took: pops + exact steps) */
 			if (!ovf && !outovf) { /* (a read finishes once in tens of thousands of iterations: five atomics instead of ten registers held across the loop) */
 				if (n_alns) atomicAdd(&stats[STAT_ALNS], (unsigned long long)n_alns);
 				if (r_vis_s) atomicAdd(&stats[STAT_VIS_SINGLE], (unsigned long long)r_vis_s);
@@ -1295,17 +1304,18 @@ __global__ __launch_bounds__(LANE_BLOCK, 2) void kl_search(DevIndex ix, const Sl
 			h.release_excess();
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			h.bstate[h.cb] = NONE32;
-			while (h.neLo | h.neHi) { const int k = h.best(nb); h.bstate[k] = NONE32; h.unmark(k); }
+			while (h.neW) { const int k = h.best(nb); h.bstate[k] = NONE32; h.unmark(k); }
 			active = false;
 		}
 	}
-	if (n_bkt) atomicAdd(&stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
+	if (lane == 0 && n_bkt) atomicAdd(&stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
 	if (parked) atomicAdd(&stats[STAT_PARKED], 1ull);
-	atomicAdd(&stats[STAT_N], (unsigned long long)n_iter);        /* total loop iterations */
-	atomicMax(&stats[STAT_N_MAX], (unsigned long long)n_iter);    /* longest lane */
-	if ((threadIdx.x & 63u) == 0) atomicAdd(&stats[STAT_WAVE_ITERS], (unsigned long long)w_iter); /* wave iterations */
+	if (lane == 0) {
+		atomicAdd(&stats[STAT_N], (unsigned long long)n_iter);            /* loop iterations of busy lanes */
+		atomicAdd(&stats[STAT_WAVE_ITERS], (unsigned long long)w_iter);   /* loop iterations of waves: the ratio = lanes busy of 64 */
+	}
 #ifdef BWB_STAMPS
-	if (n_iter) for (int k = 0; k < 16; k++) atomicAdd(&stats[STAT_STAMPS + k], seg[k]);
+	for (int k = 0; k < 16; k++) if (seg[k]) atomicAdd(&stats[STAT_STAMPS + k], seg[k]);
 #endif
 #ifdef BWB_HIST
 	hist[H_PUSH_GAP] = 0; hist[H_PUSH_MIS] = 0; hist[H_PUSH_MATCH] = 0;
