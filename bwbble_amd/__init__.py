@@ -41,6 +41,7 @@ class Stats(C.Structure):
     _fields_ = [("visits_single", C.c_uint64), ("visits_calc_d", C.c_uint64), ("visits_alphabet", C.c_uint64), ("heap_pops", C.c_uint64),
                 ("heap_pushes", C.c_uint64), ("n_alignments", C.c_uint64), ("n_overflow_reads", C.c_uint64), ("n_parked_reads", C.c_uint64),
                 ("bucket_loads_search", C.c_uint64), ("bucket_loads_calc_d", C.c_uint64), ("lane_iterations", C.c_uint64), ("wave_iterations", C.c_uint64),
+                ("heap_entries_stored", C.c_uint64), ("heap_entries_loaded", C.c_uint64), ("record_loads", C.c_uint64),
                 ("ms_calc_d", C.c_double), ("ms_search", C.c_double), ("ms_total", C.c_double),
                 ("launches_calc_d", C.c_uint32), ("launches_search", C.c_uint32)]
 

@@ -854,6 +854,7 @@ static int read_device_stats(bwb_hip_ctx *c) {
 	c->stats.bucket_loads_search = st[STAT_BKT_SEARCH]; c->stats.bucket_loads_calc_d = st[STAT_BKT_CALCD];
 	c->stats.n_parked_reads = st[STAT_PARKED];
 	c->stats.lane_iterations = st[STAT_N]; c->stats.wave_iterations = st[STAT_WAVE_ITERS];
+	c->stats.heap_entries_stored = st[STAT_ENT_ST]; c->stats.heap_entries_loaded = st[STAT_ENT_LD]; c->stats.record_loads = st[STAT_REC_LD];
 #ifdef BWB_HIST
 	{
 		static const char *hn[H_N] = { "iter", "pop", "pop_from_mirror", "pop_gapped", "pruned", "hit", "exact_start", "expand", "exact_step", "need_rank", "same_bkt", "two_bkt",

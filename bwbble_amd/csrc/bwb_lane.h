@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
                                                   Lds<u32x4> stage, Lds<u32x4> zero_row, int lane, uint32_t &n_bkt, KidCtx<P> &kc) {
 	PairInfo<P> pi;
 	pair_setup<P>(last_row, need, (P)(iL - 1), iU, lane, pi);
-	n_bkt += (uint32_t)__popcll(__ballot(pi.blkL != NONE32)) + (uint32_t)pi.nU; /* (wave-uniform: the whole wave's buckets, added up by lane 0 at the end) */
+	n_bkt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_bkt + (uint32_t)__popcll(__ballot(pi.blkL != NONE32)) + (uint32_t)pi.nU)); /* (wave-uniform: the whole wave's buckets, added up by lane 0 at the end) */
 	wave_gather<P>(buckets, pi, 0, stage, lane);
 	const Lds<u32x4> own = stage + lane * 8;
 	const int rot = (lane >> 1) & 7;
@@ -635,7 +635,8 @@ template <typename P, bool WIDE> struct LHeap {
 
 /* stores one heap entry at p and advances p */
 template <typename P, bool WIDE>
-__device__ __forceinline__ void emit_entry(uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+__device__ __forceinline__ void emit_entry(uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs, uint32_t &n_st) {
+	n_st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_st + (uint32_t)__popcll(__ballot(true)))); /* (wave-uniform, kept in a scalar register: entries stored by the lanes that are here) */
 	L = pos_enc<P>(L); U = pos_enc<P>(U);
 	if (WIDE) {
 		p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
-	uint32_t n_bkt = 0;
+	uint32_t n_bkt = 0, n_est = 0, n_eld = 0, n_rec = 0; /* wave-uniform: buckets fetched, heap entries stored / loaded, per-position records loaded */
 	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -896,8 +897,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
 		P iL = 0, iU = 0;
 		int widx = 0;
-		n_iter += (uint32_t)__popcll(__ballot(active)); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
-		w_iter++;
+		n_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_iter + (uint32_t)__popcll(__ballot(active)))); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
+		w_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w_iter + 1u));
 		HIST(H_ITER, active); HISTW(H_WAVE_ITERS, 1);
 #ifdef BWB_HIST
 		int hw_g = 0, hw_x = 0, hw_0 = 0; bool h_mirror = false;
@@ -978,6 +979,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
 		if (need_rank || (from_pop && len < kp.seed_length)) { /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
+			n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(true))));
 			const uint2 rec = recs[widx]; /* one load: D[i-1], D[i-2] | D_seed pair | seq[len - widx] */
 			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
 			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const int j = __ffs((int)gm) - 1;
 					gm &= gm - 1;
 					kid(j, h.top.L, h.top.U);
-					if (gm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, e.f, sd, eruns); /* (the last child is popped next: the register mirror is its only copy) */
+					if (gm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, e.f, sd, eruns, n_est); /* (the last child is popped next: the register mirror is its only copy) */
 				}
 				h.top.f = e.f; h.top.sa = sd; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi;
 				h.cst = st0 + (uint32_t)n; h.mark(e_score); h.top_valid = true;
@@ -1131,10 +1133,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
 						   * holds the parent's interval (a single deletion child is stored as itself) */
 							uint4 *pg = tG == 0 ? p0 : (tG == 1 ? p1 : p2);
-							if (nIns) emit_entry<P, WIDE>(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i);
+							if (nIns) emit_entry<P, WIDE>(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, n_est);
 							const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
-							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit_entry<P, WIDE>(pg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d); }
-							else if (nDel) emit_entry<P, WIDE>(pg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d);
+							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit_entry<P, WIDE>(pg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, n_est); }
+							else if (nDel) emit_entry<P, WIDE>(pg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, n_est);
 							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
 						}
 						STAMP(12);
@@ -1147,7 +1149,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								xm &= xm - 1;
 								P cl, cu;
 								kid(j, cl, cu);
-								emit_entry<P, WIDE>(px, cl, cu, f_mis, sm, eruns);
+								emit_entry<P, WIDE>(px, cl, cu, f_mis, sm, eruns, n_est);
 							}
 							if (tX == 1) p1 = px; else p0 = px;
 							uint32_t mm = matchm;
@@ -1157,7 +1159,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								kid(j, h.top.L, h.top.U);
 								/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket
 								 * being popped): the register mirror is its only copy, its slot is reserved but never written. */
-								if (mm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, f_match, sm, eruns);
+								if (mm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, f_match, sm, eruns, n_est);
 							}
 							if (matchm) { h.top.f = f_match; h.top.sa = sm; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi; top_ok = true; }
 						} else { /* mm_score == 0: one bucket, interleaved in code order */
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								am &= am - 1;
 								P cl, cu;
 								kid(j, cl, cu);
-								emit_entry<P, WIDE>(p0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
+								emit_entry<P, WIDE>(p0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns, n_est);
 							}
 						}
 						STAMP(13);
@@ -1270,6 +1272,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(15);
 		HIST(H_TOP_RELOAD, active && !h.top_valid && h.cst != NONE32);
 		if (active && !h.top_valid && h.cst != NONE32) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
+			n_eld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_eld + (uint32_t)__popcll(__ballot(true))));
 			h.load_entry(h.cst, h.top);
 			h.top_valid = true;
 		}
@@ -1309,6 +1312,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 	}
 	if (lane == 0 && n_bkt) atomicAdd(&stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
+	if (lane == 0) { atomicAdd(&stats[STAT_ENT_ST], (unsigned long long)n_est); atomicAdd(&stats[STAT_ENT_LD], (unsigned long long)n_eld); atomicAdd(&stats[STAT_REC_LD], (unsigned long long)n_rec); }
 	if (parked) atomicAdd(&stats[STAT_PARKED], 1ull);
 	if (lane == 0) {
 		atomicAdd(&stats[STAT_N], (unsigned long long)n_iter);            /* loop iterations of busy lanes */
@@ -1346,7 +1350,7 @@ template <typename P>
 __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uint64_t n, uint64_t seed, unsigned long long *checksum) {
 	__shared__ P s_base[BWB_BASE_ROWS * 16];
 	__shared__ u32x4 s_zero[8];
-	__shared__ u32x4 s_stage[LANE_BLOCK / 64][WAVE_STAGE_U4];
+	__shared__ u32x4 s_stage[LANE_BLOCK / 64][WAVE_LDS_BYTES / 16]; /* rows + exchange array */
 	if (threadIdx.x < 32) ((Lds<uint32_t>)&s_zero[0])[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
 	const uint64_t nl = (uint64_t)gridDim.x * LANE_BLOCK;

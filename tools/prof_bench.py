@@ -8,7 +8,7 @@ import bwbble_amd as bw
 work = os.environ.get("BWB_BENCH_DIR", "/tmp/bwb_bench")
 n_fwd, pool, B, nd = int(float(sys.argv[1]) * 1e6), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-fa, fq = f"{work}/genome_{n_fwd}.fa", f"{work}/reads_{n_fwd}_{pool}_100_r0.fq"
+fa, fq = f"{work}/genome_{n_fwd}.fa", f"{work}/reads_{n_fwd}_{pool}_100_i0.1_r0.fq"
 ctx = bw.Context(bw.BwtFile(fa + ".bwt"))
 seqs, lens = bw.load_fastq_codes(fq, max_reads=min(pool, B * bw.MAX_SLOTS))
 p = bw.params(["-n", nd])
