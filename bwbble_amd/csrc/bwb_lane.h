@@ -301,15 +301,15 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 
 /* ---- SA-interval list being built: add_sa_interval (align.c:93-110), tail in registers ------------ */
 template <typename P> struct ListW {
-	int sel;      /* which of the lane's two lists is being built (the buffer is base + sel * cap: no pointer kept in registers) */
 	int T;        /* intervals so far, including the open tail */
 	P tL, tU;
 };
-template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, P L, P U, int cap, bool &ovf) {
+/* the list being built is the one the current step does not read: buffer base + sel * cap (no pointer kept in registers) */
+template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, int sel, P L, P U, int cap, bool &ovf) {
 	if (l.T != 0 && L == (P)(l.tU + 1)) { l.tU = U; return; }
 	if (l.T != 0) {
 		if (l.T - 1 >= cap) { ovf = true; return; }
-		Intv<P> *buf = base + l.sel * cap;
+		Intv<P> *buf = base + sel * cap;
 		buf[l.T - 1].L = l.tL; buf[l.T - 1].U = l.tU;
 	}
 	l.tL = L; l.tU = U; l.T++;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	uint32_t rid = 0;
 	int len = 0, phase = 0, plen = 0, r = 0, z = 0, s = 0, curT = 0, cursel = 0;
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
-	ListW<P> nx; nx.sel = 0; nx.T = 0; nx.tL = nx.tU = 0;
+	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
 	int32_t nm = 0, prev_nm = 0;
 	uint32_t prev_byte = 0, cntN = 0;
 	unsigned long long vis = 0;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				seq = b.reads + (size_t)rid * b.stride;
 				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
 				cL = 0; cU = last_row; curT = 1;
-				nx.sel = 1; nx.T = 0;
+				nx.T = 0;
 				active = len > 0;
 				if (!(kp.seed_length && len > kp.seed_length)) {
 					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				P L, U;
 				kid_get<P>(kc, sb, j, L, U);
 				nm += (int32_t)(uint32_t)(U - L + 1);
-				list_add<P>(nx, lbase, L, U, cap, ovf);
+				list_add<P>(nx, lbase, cursel ^ 1, L, U, cap, ovf);
 			}
 			s++;
 		}
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			/* position finished: swap lists (inexact_match.c:234-237) */
 			cursel ^= 1;
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
-			nx.sel = cursel ^ 1; nx.T = 0; s = 0;
+			nx.T = 0; s = 0;
 			if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
 				cL = 0; cU = last_row; curT = 1; z++;
 				nm = (int32_t)(uint32_t)ix.length;
@@ -730,15 +730,17 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 	bool active = false, done = false;
 	uint32_t rid = 0, myslot = wk.slot;
-	int len = 0, mode = LMODE_POP;
+	int len = 0;
+	bool exact_mode = false;                                /* LMODE_EXACT: the lane is in an exact tail (or seeding with -P) */
 	int best_score = 0, max_diff = 0, num_best = 0, n_alns = 0;
-	int r = 0, s = 0, curT = 0, cursel = 0, r_stop = 0;     /* exact-tail state; it ends after rc[r_stop] */
+	int r = 0, s = 0, curT = 0;                             /* exact-tail state; it ends after rc[r_stop], r_stop = seeding ? len - 12 : 0 */
+	bool cursel = false;                                    /* which of the two lists the step reads; it builds the other */
 	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* exact tail: the next interval of a multi-interval list, fetched ahead */
 	bool seeding = false;                                   /* -P: the exact steps under way build the read's first heap entries */
 	uint32_t nxw = 0;                                       /* exact tail: summed width of the intervals added to the next list so far (wrapping, like the
 	                                                           reference's int num_best sum :350-352) */
 	P cL = 0, cU = 0;
-	ListW<P> nx; nx.sel = 0; nx.T = 0; nx.tL = nx.tU = 0;
+	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 	int e_score = 0;
@@ -760,14 +762,13 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		            a7 = mysave[7], a8 = mysave[8], a9 = mysave[9], a10 = mysave[10], a11 = mysave[11], a12 = mysave[12], a13 = mysave[13];
 		auto p64 = [](uint32_t lo, uint32_t hi) { return (P)(((uint64_t)hi << 32) | lo); };
 		const uint32_t fl = a0.x;
-		mode = (fl >> 1) & 1u; cursel = (fl >> 2) & 1u; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
+		exact_mode = ((fl >> 1) & 1u) != 0; cursel = ((fl >> 2) & 1u) != 0; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
 		myslot = (fl >> 8) & 0xFFu;
-		nx.sel = (int)((fl >> 6) & 1u);
 		rid = a0.y;
 		len = (int)(a0.z & 255u); best_score = (int)((a0.z >> 8) & 255u); max_diff = (int)((a0.z >> 16) & 255u); e_score = (int)(a0.z >> 24);
 		num_best = (int)a0.w;
 		n_alns = (int)a1.x; r = (int)a1.y; s = (int)a1.z; curT = (int)a1.w;
-		r_stop = (int)a2.x; nx.T = (int)a2.y; cL = p64(a2.z, a2.w);
+		nx.T = (int)a2.y; cL = p64(a2.z, a2.w);
 		cU = p64(a3.x, a3.y); nx.tL = p64(a3.z, a3.w);
 		nx.tU = p64(a4.x, a4.y); nxi.L = p64(a4.z, a4.w);
 		nxi.U = p64(a5.x, a5.y); e.L = p64(a5.z, a5.w);
@@ -826,13 +827,13 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
-				n_alns = 0; mode = LMODE_POP; active = true;
+				n_alns = 0; exact_mode = false; active = true;
 				bool ovf0 = false;
 				/* a read whose calculate_d overflowed its scratch class waits for the re-run of both kernels in a larger class */
 				const bool dfail = b.status[rid] == ST_D_OVF;
 				/* (an EMPTY read is searched like any other: its root entry is a hit with the whole index as its interval, :331-344) */
 				bool skip = cntN > kp.max_diff || unrep || dfail; /* inexact_match.c:260-266 */
-				seeding = false; r_stop = 0;
+				seeding = false;
 				if (kp.use_precalc && !skip) {
 					/* -P.  A read with an N in the last 12 bases of rc (= the first 12 of seq) gets an empty record
 					 * (inexact_match.c:129-136).  Otherwise the heap starts from the precalculated list of that 12-mer
@@ -840,10 +841,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					 * 12 exact steps are run here instead of reading the 16.7 M-list .pre table. */
 					for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) skip = true;
 					if (!skip) {
-						seeding = true; r_stop = len - PRECALC_LEN;
-						cL = 0; cU = last_row; curT = 1; cursel = 0; s = 0; r = len - 1;
-						nx.sel = 1; nx.T = 0; nxw = 0;
-						mode = LMODE_EXACT;
+						seeding = true;
+						cL = 0; cU = last_row; curT = 1; cursel = false; s = 0; r = len - 1;
+						nx.T = 0; nxw = 0;
+						exact_mode = true;
 					}
 				}
 				if (!skip && !seeding) {
@@ -870,11 +871,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* (lanes of other waves may be waiting for admission) */
 				auto lo = [](P v) { return (uint32_t)v; };
 				auto hi = [](P v) { return (uint32_t)((uint64_t)v >> 32); };
-				const uint32_t fl = 1u | ((uint32_t)mode << 1) | ((uint32_t)cursel << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
-				                    ((h.top_valid ? 1u : 0u) << 5) | ((uint32_t)nx.sel << 6) | (myslot << 8);
+				const uint32_t fl = 1u | ((exact_mode ? 1u : 0u) << 1) | ((cursel ? 1u : 0u) << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
+				                    ((h.top_valid ? 1u : 0u) << 5) | (myslot << 8);
 				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)best_score << 8) | ((uint32_t)max_diff << 16) | ((uint32_t)e_score << 24), (uint32_t)num_best);
 				mysave[1] = make_uint4((uint32_t)n_alns, (uint32_t)r, (uint32_t)s, (uint32_t)curT);
-				mysave[2] = make_uint4((uint32_t)r_stop, (uint32_t)nx.T, lo(cL), hi(cL));
+				mysave[2] = make_uint4(0u, (uint32_t)nx.T, lo(cL), hi(cL));
 				mysave[3] = make_uint4(lo(cU), hi(cU), lo(nx.tL), hi(nx.tL));
 				mysave[4] = make_uint4(lo(nx.tU), hi(nx.tU), lo(nxi.L), hi(nxi.L));
 				mysave[5] = make_uint4(lo(nxi.U), hi(nxi.U), lo(e.L), hi(e.L));
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(0);
 		/* ---- A: pick the SA interval of this iteration ---- */
 		if (!active) { /* idle lanes only help with the cooperative rank below */ }
-		else if (mode == LMODE_POP) {
+		else if (!exact_mode) {
 			if (h.num_entries == 0 || h.num_entries > kp.max_entries) finish = true; /* :293,299 */
 			else {
 				const int bk = h.best(nb);
@@ -955,22 +956,22 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			widx = r + 1;
 			if (s == curT - 1) { iL = cL; iU = cU; }
 			else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous step */
-			else { const Intv<P> v = (lbase + cursel * lcap)[s]; iL = v.L; iU = v.U; }
+			else { const Intv<P> v = (lbase + (cursel ? lcap : 0))[s]; iL = v.L; iU = v.U; }
 			need_rank = true;
 		}
 
 #ifdef BWB_HIST
-		HIST(H_POP, active && mode == LMODE_POP && (from_pop || finish)); HIST(H_POP_GAPPED, from_pop && ((e.f >> 16) != 0)); HIST(H_POP_FROM_MIRROR, from_pop && h_mirror);
-		HIST(H_EXACT_STEP, active && mode == LMODE_EXACT); HIST(H_NEED_RANK, need_rank); HIST(H_ALPHA, need_rank && alpha);
-		HIST(H_EXACT_MULTI, active && mode == LMODE_EXACT && curT > 1); HIST(H_ALLOC, from_pop && is_group);
+		HIST(H_POP, active && !exact_mode && (from_pop || finish)); HIST(H_POP_GAPPED, from_pop && ((e.f >> 16) != 0)); HIST(H_POP_FROM_MIRROR, from_pop && h_mirror);
+		HIST(H_EXACT_STEP, active && exact_mode); HIST(H_NEED_RANK, need_rank); HIST(H_ALPHA, need_rank && alpha);
+		HIST(H_EXACT_MULTI, active && exact_mode && curT > 1); HIST(H_ALLOC, from_pop && is_group);
 		const P hw_ = (P)(iU - iL + 1);
 		const bool hsame_ = need_rank && ((P)(iL - 1) >> 7) == (iU >> 7) && iL != 0 && iU != last_row;
 		HIST(H_SAME_BKT, hsame_); HIST(H_TWO_BKT, need_rank && !hsame_);
 		HIST(H_W1, need_rank && hw_ == 1); HIST(H_W2, need_rank && hw_ == 2); HIST(H_W4, need_rank && hw_ > 2 && hw_ <= 4); HIST(H_W8, need_rank && hw_ > 4 && hw_ <= 8);
 		HIST(H_W32, need_rank && hw_ > 8 && hw_ <= 32); HIST(H_W128, need_rank && hw_ > 32 && hw_ <= 128); HIST(H_WBIG, need_rank && (hw_ > 128 || hw_ == 0));
 		HISTW(H_WAVE_ANY_TWO_BKT, __any(need_rank && !hsame_) ? 1 : 0); HISTW(H_WAVE_ANY_WIDE8, __any(need_rank && (hw_ > 8 || hw_ == 0)) ? 1 : 0);
-		HISTW(H_WAVE_ANY_EXACT, __any(active && mode == LMODE_EXACT) ? 1 : 0); HISTW(H_WAVE_ANY_EXPAND, __any(from_pop && need_rank) ? 1 : 0);
-		HISTW(H_WAVE_ALL_EXACT, __all(!active || mode == LMODE_EXACT) ? 1 : 0);
+		HISTW(H_WAVE_ANY_EXACT, __any(active && exact_mode) ? 1 : 0); HISTW(H_WAVE_ANY_EXPAND, __any(from_pop && need_rank) ? 1 : 0);
+		HISTW(H_WAVE_ALL_EXACT, __all(!active || exact_mode) ? 1 : 0);
 #endif
 		STAMP(1);
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
@@ -1011,7 +1012,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(3);
 
 		/* ---- C: act on it ---- */
-		bool exact_step = active && (mode == LMODE_EXACT);
+		bool exact_step = active && (exact_mode);
 		if (from_pop && is_group) {
 			/* ---- a deletion group has reached the top of its bucket: its children take its place ---- */
 			const int n = __popc(ne);
@@ -1055,9 +1056,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					else if (num_best > kp.max_best) finish = true;
 					else add_aln(e.L, e.U, e_score, e_alen);
 				} else if (diff_left == 0) { /* exact tail :345-375: its first step uses the children just computed */
-					cL = e.L; cU = e.U; curT = 1; cursel = 0; s = 0; r = e_i - 1;
-					nx.sel = 1; nx.T = 0; nxw = 0;
-					mode = LMODE_EXACT;
+					cL = e.L; cU = e.U; curT = 1; cursel = false; s = 0; r = e_i - 1;
+					nx.T = 0; nxw = 0;
+					exact_mode = true;
 					exact_step = true;
 				} else {
 					STAMP(8);
@@ -1201,24 +1202,24 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					P cl, cu;
 					kid(j, cl, cu);
 					nxw += (uint32_t)(cu - cl + 1);
-					list_add<P>(nx, lbase, cl, cu, lcap, ovf);
+					list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap, ovf);
 				}
 				s++;
 				if (!ovf && s >= curT) {
-					cursel ^= 1; curT = nx.T; cL = nx.tL; cU = nx.tU;
-					nx.sel = cursel ^ 1; nx.T = 0; s = 0;
+					cursel = !cursel; curT = nx.T; cL = nx.tL; cU = nx.tU;
+					nx.T = 0; s = 0;
 					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
-					else { r--; if (r < r_stop) exact_done = true; }
+					else { r--; if (r < (seeding ? len - PRECALC_LEN : 0)) exact_done = true; }
 				}
 				/* the interval of the next step, when it is not the list's tail (which is in registers): on its way now */
 				nxi_valid = !ovf && !exact_done && s != curT - 1;
-				if (nxi_valid) nxi = (lbase + cursel * lcap)[s];
+				if (nxi_valid) nxi = (lbase + (cursel ? lcap : 0))[s];
 			}
 			STAMP(6);
 			if (exact_done && !ovf && seeding) {
 				/* :269-279: one entry per interval, i = readLen - 12, a 12-long all-M path; no interval: no alignment */
-				mode = LMODE_POP; seeding = false; r_stop = 0;
+				exact_mode = false; seeding = false;
 				if (curT == 0) finish = true;
 				else {
 					LEntry<P> ent; ent.f = (uint32_t)(len - PRECALC_LEN); ent.sa = (uint32_t)STATE_M | ((uint32_t)PRECALC_LEN << 2); ent.runsLo = ent.runsHi = ~0u;
@@ -1226,14 +1227,14 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					uint32_t st = h.cst; /* bucket 0 of the empty heap */
 					for (int k = 0; k < curT && !ovf; k++) {
 						if (k == curT - 1) { ent.L = cL; ent.U = cU; }
-						else { const Intv<P> v = (lbase + cursel * lcap)[k]; ent.L = v.L; ent.U = v.U; }
+						else { const Intv<P> v = (lbase + (cursel ? lcap : 0))[k]; ent.L = v.L; ent.U = v.U; }
 						st = h.reserve(st, 1, ovf);
 						if (!ovf) { st++; h.store_entry(st, ent); }
 					}
 					if (!ovf) { h.cst = st; h.mark(0); h.num_entries = curT; h.top = ent; h.top_valid = true; r_push += (uint32_t)curT; }
 				}
 			} else if (exact_done && !ovf) {
-				mode = LMODE_POP;
+				exact_mode = false;
 				if (curT != 0) { /* matches found :347-371 */
 					const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
 					if (n_alns == 0) {
@@ -1249,7 +1250,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					if (brk) finish = true;
 					else {
 						const int alen2 = ((int)((e.sa >> 2) & 255u) + e_i) & 255; /* :365 */
-						const Intv<P> *lst = lbase + cursel * lcap;
+						const Intv<P> *lst = lbase + (cursel ? lcap : 0);
 						int k = 0;
 						if (e_go == 0) { /* no duplicate check (align.c:273-280 applies to gapped entries): four list loads in flight at a time */
 							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)sc.acap; k += 4) {
