@@ -143,17 +143,20 @@ def main():
     ctx = bw.Context(bwt, device=device)
     t_ctx = time.time() - t0
     B = a.reads
-    nb = max(1, min(bw.MAX_SLOTS, a.pool // B))  # batches resident in HBM; step s runs batch s % nb
-    batch = lambda j: (seqs[j * B:(j + 1) * B], lens[j * B:(j + 1) * B])
-    for j in range(nb):
+    nb = max(1, a.pool // B)  # distinct batches of the pool
+    ns = bw.MAX_SLOTS if B < 2000000 else 4  # batches resident in HBM (slots of the context): slot j holds batch j mod nb; step s runs slot s mod ns.
+                              # A slot runs again only when its previous pass is complete - its heaviest read has ns - 1 further slices for
+                              # that, which is why small batches on a small index want all the slots
+    batch = lambda j: (seqs[(j % nb) * B:(j % nb + 1) * B], lens[(j % nb) * B:(j % nb + 1) * B])
+    for j in range(ns):
         ctx.slot_upload(j, p, *batch(j))
     ctx.flush()
 
     def run_steps(k):
         """k steps queued back to back; returns when all of them are complete"""
         for s in range(k):
-            slot = s % nb
-            if s >= nb:
+            slot = s % ns
+            if s >= ns:
                 ctx.slot_wait(slot)  # its previous pass must be complete before the batch runs again
             ctx.slot_submit(slot)
         ctx.flush()
@@ -224,7 +227,8 @@ def main():
         "n_gpus": world if not share else len({r % max(ndev, 1) for r in range(world)}), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if bwt.length < 0xFFFFFFFF else "u64", "data": "synthetic",
         "config": {"workload": f"{scale} synthetic multi-genome: {n_fwd} fwd chars (BWT length {bwt.length}), FASTQ shard of {a.pool} x {a.read_len} bp "
-                               f"reads per GPU, one step = one resident batch of {B} reads (step s runs batch s mod {nb}), align -n {a.ndiff} (other params default)",
+                               f"reads per GPU, one step = one resident batch of {B} reads (step s runs batch s mod {nb} from slot s mod {ns}), align {' '.join(flags)} (other params default)",
+                   "name": a.config + ("" if world == 1 or a.config != "C3" else " (C4: the C3 workload sharded over the GPUs)"), "genome_mb": a.genome_mb, "flags": " ".join(flags),
                    "reads_per_gpu_per_step": B, "read_pool_per_gpu": a.pool, "batches_resident": nb, "read_len": a.read_len, "max_diff": a.ndiff,
                    "bwt_length": int(bwt.length), "sharding": f"reads x{world} (contiguous shards of one logical FASTQ), index replicated",
                    "steps_are_pipelined": "a slice parks its unfinished reads for the next step's slice; the timed region ends with a flush"},
@@ -254,7 +258,7 @@ def main():
                                               "note": "informational: this run's reads/s per GPU over a stored 1-GPU line of the same workload (the driver computes the official curve)"}
     if world == 1 and not a.no_extras:
         out["cpu_baseline"] = cpu_baseline(a, fa, fq, flags, off0, alns0, bw)
-        out["end_to_end"] = end_to_end(ctx, p, batch, nb, B, value)
+        out["end_to_end"] = end_to_end(ctx, p, batch, min(nb, 4), B, value)
         out["rank_micro"] = rank_micro(ctx, index_mb)
         if a.ndiff != 0:
             out["also"] = {"n0": also_n0(ctx, bw, batch, nb, B)}
@@ -300,8 +304,7 @@ def stored_n1_value(a):
         except Exception:
             continue
         c = j.get("config", {})
-        if j.get("n_gpus") == 1 and (c.get("bwt_length"), c.get("read_len"), c.get("max_diff")) and c.get("read_len") == a.read_len and c.get("max_diff") == a.ndiff \
-                and abs(c.get("bwt_length", 0) / 2.2e6 - a.genome_mb) < 0.05 * a.genome_mb:
+        if j.get("n_gpus") == 1 and (c.get("genome_mb"), c.get("read_len"), c.get("max_diff")) == (a.genome_mb, a.read_len, a.ndiff):
             return {"value": j["value"], "source": os.path.relpath(f, ROOT)}
     return None
 

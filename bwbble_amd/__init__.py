@@ -22,7 +22,7 @@ EXPORTS = [
     "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate",
     "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush",
 ]
-MAX_SLOTS = 4  # BWB_MAX_SLOTS
+MAX_SLOTS = 8  # BWB_MAX_SLOTS
 
 
 class Params(C.Structure):

@@ -278,7 +278,10 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * 32), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * 32);
 	size_t slot_bytes = 0;
 	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * 32);
-	const size_t reserve = cls1 + cls2 + 3 * slot_bytes + ((size_t)4 << 30);
+	/* (further slots: all of them when batches are small - that is when a stream needs them, DESIGN.md section 2.3 -, three more when one
+	 * slot is gigabytes: a caller that streams 2.5 M-read batches through more than four slots should set BWB_POOL_GB) */
+	const size_t more_slots = slot_bytes > ((size_t)1 << 30) ? 3 : BWB_MAX_SLOTS - 1;
+	const size_t reserve = cls1 + cls2 + more_slots * slot_bytes + ((size_t)4 << 30);
 	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
 	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
@@ -309,6 +312,20 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 			if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
 			if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
 			if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
+			/* A slice's blocks must all be resident at once: a parked read only moves while its block runs, and a block that had to
+			 * wait for another one to leave would find the cursor exhausted and park again at once.  So never more blocks per CU than
+			 * the runtime says fit (registers, LDS). */
+			{
+				int occ = 0;
+				const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true> : (const void *)kl_search<uint32_t, false>)
+				                          : (c->wide ? (const void *)kl_search<uint64_t, true> : (const void *)kl_search<uint64_t, false>);
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
+					if (c->dbg || occ < c->bpc_search) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU (asked for %d)\n", occ, LANE_BLOCK, c->bpc_search);
+					c->bpc_search = std::min(c->bpc_search, occ);
+				}
+				const void *kd = c->pos32 ? (const void *)kl_calc_d<uint32_t> : (const void *)kl_calc_d<uint64_t>;
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) c->bpc_calcd = std::min(c->bpc_calcd, occ);
+			}
 		}
 		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 4096; acap = 256;
 	} else if (k == 1) {

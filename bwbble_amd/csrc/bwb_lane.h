@@ -173,10 +173,12 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
  * `first` = code of the block's first character (bwt.c:780).  One sub-block at a time: 4 plane words live. */
 template <int HALF>
 __device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[8], uint32_t &first) {
+	u32x4 p = row[(4 + rot) & 7];
+	first = (p.x & 1u) | ((p.y & 1u) << 1) | ((p.z & 1u) << 2) | ((p.w & 1u) << 3);
 #pragma unroll
 	for (int w = 0; w < 4; w++) {
-		const u32x4 p = row[(4 + w + rot) & 7];
-		if (w == 0) first = (p.x & 1u) | ((p.y & 1u) << 1) | ((p.z & 1u) << 2) | ((p.w & 1u) << 3);
+		u32x4 pn = p;
+		if (w < 3) pn = row[(4 + w + 1 + rot) & 7]; /* the next sub-block's planes are on their way while this one is counted */
 		const int nh = hi + 1 - 32 * w, nl = lo - 32 * w; /* characters [0, nh) minus [0, nl) of this sub-block */
 		const uint32_t mh = nh <= 0 ? 0u : (nh >= 32 ? 0xFFFFFFFFu : ((1u << nh) - 1u));
 		const uint32_t ml = nl <= 0 ? 0u : (nl >= 32 ? 0xFFFFFFFFu : ((1u << nl) - 1u));
@@ -186,6 +188,7 @@ __device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int 
 #pragma unroll
 		for (int c = 0; c < 8; c++) acc[c] += __popc(a[c & 3] & b[c >> 2]);
 		__builtin_amdgcn_sched_barrier(0); /* (keeps the four sub-blocks apart: interleaved they need 4 x the registers) */
+		p = pn;
 	}
 }
 /* index of code j in the count-slice order */

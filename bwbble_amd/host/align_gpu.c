@@ -192,6 +192,18 @@ int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_
 	t = wall();
 	reads_t *reads = fastq2reads(readsFname);
 	printf("Total read loading time: %.2f sec\n", wall() - t);
+	if (params->use_precalc) { /* align.c:59-65: the first `align -P` on an index leaves <fasta>.pre behind (precalc.c: written, never read) */
+		char *preFname = (char *)malloc(L);
+		snprintf(preFname, L, "%s.pre", fastaFname);
+		FILE *pf = fopen(preFname, "r");
+		if (pf) fclose(pf);
+		else {
+			t = wall();
+			precalc_sa_intervals(BWT, params, preFname);
+			printf("Total pre-calculated intervals time: %.2f sec\n", wall() - t);
+		}
+		free(preFname);
+	}
 	t = wall();
 	align_reads_inexact_gpu(BWT, reads, NULL, params, alnsFname, n_gpus);   /* the seam: align.c:72-76 */
 	printf("Total read alignment time: %.2f sec\n", wall() - t);

@@ -87,6 +87,9 @@ void set_default_aln_params(aln_params_t *params);                     /* align.
 int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_t *params, int n_gpus); /* align.c:40-87 */
 int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_intervals, aln_params_t *params, char *alnFname, int n_gpus);
 
+/* precalc.c */
+void precalc_sa_intervals(bwt_t *BWT, const aln_params_t *params, const char *preFname); /* align.c:200-224: writes <fasta>.pre */
+
 /* sam.c */
 void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFname, int is_multiref, int max_diff, int n_gpus); /* align.c:494-556 */
 

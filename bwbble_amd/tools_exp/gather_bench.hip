@@ -4,7 +4,12 @@
 //   coop      : the wave loads the same 64 buckets cooperatively - instruction r: lane l loads slice (l & 7) of the bucket of
 //               lane 8r + (l >> 3), so one instruction touches 8 lines instead of 64 - and transposes through LDS
 //   *_nop     : the same without the rank ALU (xor of the words), to separate memory from ALU
-// usage: gather_bench <table_MiB> [window_MiB]   (window: positions are drawn from the first window_MiB only)
+//   meta8/16  : (round 3) the shape of the search kernel's per-lane METADATA - every lane loads 8 or 16 bytes from its own random
+//               place of the table (a per-position record, a heap entry): 64 different 64-byte sectors per wave instruction.
+//               Under `rocprofv3 --pmc FETCH_SIZE` (tools/pmc_traffic.sh) this calibrates how the counter tallies such requests:
+//               FETCH_SIZE x 1024 / (loads x 64 B) - next to the 0.50 it shows for 128-byte bucket requests (k_coop, k_lane).
+// usage: gather_bench <table_MiB> [window_MiB] [meta]  (window: positions are drawn from the first window_MiB only; meta: only the
+//        calibration kernels k_coop<false,1>, k_meta<8>, k_meta<16>, one launch each, 2^27 loads)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -96,6 +101,19 @@ __global__ __launch_bounds__(256) void k_coop(const uint4* __restrict__ buckets,
   atomicAdd(out, acc);
 }
 
+// one W-byte load per lane from a random W-aligned place of the table
+template <int W>
+__global__ __launch_bounds__(256) void k_meta(const uint4* __restrict__ table, uint64_t nbytes, uint64_t n, uint64_t seed, unsigned long long* out) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long acc = 0;
+  for (uint64_t q = tid; q < n; q += nth) {
+    const uint64_t off = (mix(q * 0x9E3779B97F4A7C15ull + seed) % (nbytes / W)) * W;
+    if (W == 8) { const uint2 v = *(const uint2*)((const char*)table + off); acc += v.x ^ v.y; }
+    else { const uint4 v = *(const uint4*)((const char*)table + off); acc += v.x ^ v.y ^ v.z ^ v.w; }
+  }
+  atomicAdd(out, acc);
+}
+
 int main(int argc, char** argv) {
   const uint64_t mib = argc > 1 ? strtoull(argv[1], 0, 10) : 1024, win = argc > 2 ? strtoull(argv[2], 0, 10) : mib;
   const uint64_t bytes = mib << 20, npos = (win << 20) - 1; // one position per byte of the window: bucket = pos >> 7
@@ -117,6 +135,14 @@ int main(int argc, char** argv) {
     }
     printf("%-22s grid %5d: %8.3f ms  %6.2f Gvisit/s  %7.1f GB/s(128B)\n", name, grid, best, n / best / 1e6, n * 128.0 / best / 1e6);
   };
+  if (argc > 3) { // calibration launches for the PMC passes: known numbers of requests of each shape
+    hipLaunchKernelGGL((k_coop<false, 1>), dim3(1024), dim3(256), 0, 0, d, npos, n, 11ull, out);
+    hipLaunchKernelGGL((k_meta<8>), dim3(2048), dim3(256), 0, 0, d, (win << 20), n, 12ull, out);
+    hipLaunchKernelGGL((k_meta<16>), dim3(2048), dim3(256), 0, 0, d, (win << 20), n, 13ull, out);
+    hipDeviceSynchronize();
+    printf("calibration: k_coop<false,1> %llu x 128 B bucket requests; k_meta<8>, k_meta<16> %llu loads each (one 64-byte sector per load)\n", (unsigned long long)n, (unsigned long long)n);
+    return 0;
+  }
   for (int grid : {512, 1024, 2048}) {
     run(k_lane<false, 1>, "lane_nop U=1", grid);
     run(k_lane<false, 2>, "lane_nop U=2", grid);

@@ -125,7 +125,7 @@ int bwb_hip_reset_stats(bwb_hip_ctx *ctx);
  * that happens to process the read).  The library reproduces the serial behaviour: inside a batch it knows the order; for
  * the head of a batch the caller passes that last longer read of the earlier batches as carry_seq/carry_len (read->seq
  * codes; NULL/0 = none, which is also what batch_upload/align_batch assume). */
-#define BWB_MAX_SLOTS 4
+#define BWB_MAX_SLOTS 8
 int bwb_hip_slot_upload(bwb_hip_ctx *ctx, int slot, const bwb_params *p, const uint8_t *reads_fwd, const uint16_t *lens,
                         uint32_t n_reads, uint32_t stride, const uint8_t *carry_seq, uint32_t carry_len);
 int bwb_hip_slot_submit(bwb_hip_ctx *ctx, int slot);

@@ -63,6 +63,26 @@ def test_cli_align_writes_reference_aln(toy_dir, golden, name):
 
 
 @pytest.mark.gpu
+def test_cli_align_P_leaves_the_reference_pre_table(toy_dir, golden):
+    """The first `align -P` on an index writes <fasta>.pre like the reference does (align.c:59-65, 200-224): 16.7 M interval lists,
+    74 MB for the toy index - byte-identical to the reference's table (its SHA-256 is the committed fixture; host/precalc.c)."""
+    import hashlib
+    pre = toy_dir / "toy.fa.pre"
+    if pre.exists():
+        pre.unlink()
+    log = run([bw.HOST_BIN, "align", "-P", "-n", "0", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(toy_dir / "pre_p0.aln")])
+    assert "Pre-calculating SA intervals" in log and pre.exists()
+    h = hashlib.sha256()
+    with open(pre, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    assert h.hexdigest() == open(os.path.join(golden, "toy.fa.pre.sha256")).read().split()[0]
+    assert open(toy_dir / "pre_p0.aln", "rb").read() == open(os.path.join(golden, "toy_p0.aln"), "rb").read()
+    log = run([bw.HOST_BIN, "align", "-P", "-n", "0", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(toy_dir / "pre_p0b.aln")])
+    assert "Pre-calculating" not in log  # an existing table is left alone
+
+
+@pytest.mark.gpu
 def test_cli_align_multi_chunk_order(toy_dir, golden):
     """Chunks pulled by the per-GPU host threads are written back in input order."""
     out = toy_dir / "chunks.aln"
