@@ -336,7 +336,8 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	const uint32_t nslots = blocks * LANE_BLOCK;
 	const size_t isz = c->pos32 ? 8 : 16;
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-	const size_t b_bstate = al((size_t)BSTATE_ROW * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
+	const uint32_t brow = std::max<uint32_t>(BSTATE_ROW_MIN, ((uint32_t)c->kp.num_buckets + 63u) & ~63u);
+	const size_t b_bstate = al((size_t)brow * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
 	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16);
 	/* class 0 runs kl_calc_d of the next batch while parked reads keep their lists: it gets a second set; the re-run classes
 	 * are drained before anything else uses them */
@@ -359,7 +360,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.save = (uint4 *)base; base += b_save;
 	s.sc.blocksave = (uint32_t *)base;
 	s.sc.winfo = nullptr;
-	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = 0;
+	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = 0; s.sc.brow = brow;
 	s.sc.keep = c->keep;
 	s.blocks = blocks;
 	s.ready = true;
@@ -398,7 +399,7 @@ static int check_params(const bwb_params *p, int *nb_out) {
 	if (p->mm_score < 0 || p->gapo_score < 0 || p->gape_score < 0) return fail(BWB_E_ARG, "negative penalties are not supported");
 	if (p->mm_score > 63 || p->gapo_score > 63 || p->gape_score > 63) return fail(BWB_E_ARG, "penalties (-M, -O, -E) above 63 are not supported on the GPU path");
 	const int nb = (p->max_diff + 1) * p->mm_score + (p->max_gapo + 1) * p->gapo_score + (p->max_gape + 1) * p->gape_score; /* heap_init :513 */
-	if (nb < 1 || nb > 128) return fail(BWB_E_ARG, "score range (heap buckets) must be in [1,128]");
+	if (nb < 1 || nb > 1024) return fail(BWB_E_ARG, "score range (heap buckets = (n+1) M + (o+1) O + (e+1) E) must be in [1,1024]");
 	if (p->max_entries < 1) return fail(BWB_E_ARG, "max_entries must be positive");
 	*nb_out = nb;
 	return BWB_OK;

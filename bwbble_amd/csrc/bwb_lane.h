@@ -9,11 +9,12 @@
  *            as a mode of the same per-lane loop: every loop iteration of every lane is one
  *            rank visit pair (positions L-1 and U of one SA interval).
  *
- * Why one read per lane: a rank visit is 8 x global_load_dwordx4 of one 128-byte bucket per lane.
- * Measured on MI355X (bwbble_amd/tools_exp/lane_bench.hip) these fully divergent 128-B gathers run
- * at 50-54 G visits/s from the Infinity Cache and 40-43 G visits/s (5.2-5.5 TB/s) from HBM, and
- * all control logic serves 64 reads per wave instruction instead of 8 (the octet version was
- * VALU-bound at ~4 us per iteration).  Lanes pull reads from a global cursor (work stealing).
+ * Why one read per lane: all control logic (pop, prune checks, allow flags, heap bookkeeping) serves 64 reads per wave instruction;
+ * the first version of this path gave a read to an octet of lanes and was VALU-bound at 8 reads per wave instruction.  A rank visit
+ * needs one 128-byte bucket per lane: the wave gathers the 64 (+ the second buckets of the pairs that straddle two) cooperatively
+ * into LDS - 8 lines of 128 contiguous bytes per instruction instead of 64 different ones, which at GRCh37 scale is 50 against
+ * 10.9 G buckets/s (address translation, not HBM, binds the per-lane shape; tools_exp/gather_bench.hip) - and every lane ranks its
+ * own rows straight from LDS (wave_children).  Lanes pull reads from a global cursor (work stealing).
  *
  * Per-lane memory (global, private to the lane while it owns a read):
  *   heap    : chains of 64-slot chunks; a lane owns a private run of `keep` chunks, what a read takes beyond them comes
@@ -42,7 +43,7 @@
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define CHUNK_SLOTS 64          /* slot 0 is the header: 63 entries per chunk */
 #define POOL_REGIONS 8
-#define BSTATE_ROW 128          /* bucket states per lane: the score range is at most 128 buckets (bwb_hip_batch_upload) */
+#define BSTATE_ROW_MIN 128      /* bucket states per lane (LaneScratch::brow): at least this many, else the score range rounded up to 64 (at most 1024 buckets, bwb_hip.hip check_params) */
 #define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 #define SAVE_U4 16               /* uint4 per lane in the save area */
@@ -64,6 +65,7 @@ struct LaneScratch {
 	uint4 *alns;                /* [nslots][acap*2] */
 	uint2 *winfo;               /* [nslots][wstride] */
 	uint32_t nslots, lcap, acap, wstride;
+	uint32_t brow;              /* bucket states per lane */
 };
 
 /* ---- per-lane rank from the wave's LDS staging area ------------------------------------------------------------------------
@@ -379,8 +381,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				nx.T = 0;
 				active = len > 0;
 				if (!(kp.seed_length && len > kp.seed_length)) {
-					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads
-					 * whatever its thread's buffer holds.  We define that as the calloc'd zeros (num_diff 0, equal widths). */
+					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads whatever
+					 * its buffer holds: the bounds of the last longer read before this one in the file (serial path, one buffer:
+					 * inexact_match.c:35) - k_dseed_inherit copies those in afterwards - or the calloc'd zeros written here (num_diff 0,
+					 * equal widths) when there is no such read. */
 					uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
 					for (int i = 0; i <= len; i++) { /* (i = 0: the hit check of a read shorter than the seed consults D_seed too, :324-328) */
 						const int si = i - (len - kp.seed_length);
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	const uint32_t region = blockIdx.x % sc.n_regions;
 	h.pbase = ((blockIdx.x / sc.n_regions) * LANE_BLOCK + threadIdx.x) * sc.keep;
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
-	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW; h.nslots = sc.nslots;
+	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slotv * sc.brow; h.nslots = sc.nslots;
 	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.reset();
 
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	for (;;) {
 		STAMP(7);
 		asm volatile("" : "+v"(slotv));
-		h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW;
+		h.bstate = sc.bstate + (size_t)slotv * sc.brow;
 		bool admit = !active && !done;
 		if (admit) {
 			/* admission: what a read will need is not known in advance, and a read that finds the pool empty is given up and
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		STAMP(14);
 		asm volatile("" : "+v"(slotv));
-		h.bstate = sc.bstate + (size_t)slotv * BSTATE_ROW;
+		h.bstate = sc.bstate + (size_t)slotv * sc.brow;
 		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504) */
 		const int e_state = (int)(e.sa & 3u);
 		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);

@@ -105,6 +105,18 @@ def test_cli_align_two_workers_on_one_device(toy_dir, golden):
 
 
 @pytest.mark.gpu
+def test_cli_align_four_workers_on_one_device(toy_dir, golden):
+    """`align -g 4` (the 8-GPU path of config C4 with as many workers as one device reasonably takes): four host threads and
+    contexts on device 0, 7 chunks, ordered writer - the reference's bytes."""
+    out = toy_dir / "g4.aln"
+    env = dict(os.environ, BWB_DEVICE_MAP="0,0,0,0", BWB_CHUNK="97", BWB_POOL_GB="1", BWB_BLOCKS_PER_CU="1", BWB_CALCD_BLOCKS_PER_CU="1")
+    log = subprocess.run([bw.HOST_BIN, "align", "-n", "3", "-g", "4", str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(out)],
+                         check=True, env=env, stdout=subprocess.PIPE, text=True).stdout
+    assert "GPUs: 4" in log
+    assert open(out, "rb").read() == open(os.path.join(golden, "toy_n3.aln"), "rb").read()
+
+
+@pytest.mark.gpu
 def test_cli_more_gpus_than_present_fails_loudly(toy_dir, golden):
     n = bw.device_count()
     r = subprocess.run([bw.HOST_BIN, "align", "-g", str(n + 1), str(toy_dir / "toy.fa"), os.path.join(golden, "toy.fq"), str(toy_dir / "y.aln")],
@@ -227,18 +239,24 @@ def test_cli_short_reads_match_serial_reference(toy_dir, golden, chunk):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_shard_one_fastq(built, tmp_path):
-    """bench.py --gpus 2 launches its own two ranks (here both on GPU 0, BWB_BENCH_SHARE_DEVICE): the index is replicated, rank r
-    aligns shard r of the logical FASTQ, every rank re-aligns a sample of its neighbour's shard and the checksums must agree."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_ranks_shard_one_fastq(built, tmp_path, ranks):
+    """bench.py --gpus N launches its own N ranks (here all on GPU 0, BWB_BENCH_SHARE_DEVICE): the index is replicated, rank r
+    aligns shard r of the logical FASTQ, every rank re-aligns a sample of its neighbour's shard and the checksums must agree;
+    the line carries every rank's own rate (the 8-GPU protocol of config C4, as far as one device can exercise it)."""
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BWB_BENCH_SHARE_DEVICE="1", BWB_POOL_GB="2", BWB_BENCH_DIR=str(tmp_path))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--genome-mb", "2", "--pool", "24000", "--reads", "6000",
-                        "--steps", "3", "--warmup", "1", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    env = dict(os.environ, BWB_BENCH_SHARE_DEVICE="1", BWB_POOL_GB="2", BWB_BENCH_DIR=str(tmp_path), BWB_BLOCKS_PER_CU="1", BWB_CALCD_BLOCKS_PER_CU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--genome-mb", "2", "--pool", "24000", "--reads", "6000",
+                        "--steps", "3", "--warmup", "1", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
     assert line["shard_sample_parity"] is True and line["config"]["reads_per_gpu_per_step"] == 6000 and line["value"] > 0
+    assert 0 < line["per_rank_reads_per_s"]["min"] <= line["per_rank_reads_per_s"]["max"]
+    assert line["roofline"]["frac"] <= 1.0 and all(k["device_frac"] <= 1.0 for k in line["roofline"]["kernels"].values())
+    if ranks != 2:
+        return
     # asking for more ranks than the launcher started is an error, not a silent one-GPU run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--no-extras"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
