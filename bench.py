@@ -144,7 +144,7 @@ def main():
     t_ctx = time.time() - t0
     B = a.reads
     nb = max(1, a.pool // B)  # distinct batches of the pool
-    ns = bw.MAX_SLOTS if B < 2000000 else 4  # batches resident in HBM (slots of the context): slot j holds batch j mod nb; step s runs slot s mod ns.
+    ns = bw.MAX_SLOTS  # batches resident in HBM (slots of the context): slot j holds batch j mod nb; step s runs slot s mod ns.
                               # A slot runs again only when its previous pass is complete - its heaviest read has ns - 1 further slices for
                               # that, which is why small batches on a small index want all the slots
     batch = lambda j: (seqs[(j % nb) * B:(j % nb + 1) * B], lens[(j % nb) * B:(j % nb + 1) * B])

@@ -278,9 +278,9 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * 32), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * 32);
 	size_t slot_bytes = 0;
 	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * 32);
-	/* (further slots: all of them when batches are small - that is when a stream needs them, DESIGN.md section 2.3 -, three more when one
-	 * slot is gigabytes: a caller that streams 2.5 M-read batches through more than four slots should set BWB_POOL_GB) */
-	const size_t more_slots = slot_bytes > ((size_t)1 << 30) ? 3 : BWB_MAX_SLOTS - 1;
+	/* (every further slot like the largest so far: a stream needs them all - the heaviest reads of a batch take several slices'
+	 * time, DESIGN.md section 2.3 - and 8 x 3 GB is little next to the pool) */
+	const size_t more_slots = BWB_MAX_SLOTS - 1;
 	const size_t reserve = cls1 + cls2 + more_slots * slot_bytes + ((size_t)4 << 30);
 	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the

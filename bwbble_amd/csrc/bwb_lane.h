@@ -358,6 +358,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	bool active = false, done = false;
 	uint32_t rid = 0;
 	int len = 0, phase = 0, plen = 0, r = 0, z = 0, s = 0, curT = 0, cursel = 0;
+	int c = 4, cnext = 4; /* seq[r] and seq[r - 1]: loaded once per position, one position ahead (round 2 loaded seq[r] in every iteration) */
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
 	int32_t nm = 0, prev_nm = 0;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				r_vis = 0;
 				seq = b.reads + (size_t)rid * b.stride;
 				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
+				c = len > 0 ? seq[len - 1] : 4; cnext = len > 1 ? seq[len - 2] : 4;
 				cL = 0; cU = last_row; curT = 1;
 				nx.T = 0;
 				active = len > 0;
@@ -397,10 +399,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			}
 		}
 		if (__all(done)) break;
-		int c = 4;
 		P iL = 0, iU = 0;
 		if (active) {
-			c = seq[r];
 			if (c > 3 && phase == 0) cntN++;
 			if (c <= 3) {
 				if (s == curT - 1) { iL = cL; iU = cU; }
@@ -451,6 +451,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				dst[0] = z; dst[1] = nm;
 			}
 			prev_nm = nm; nm = 0; r--;
+			if (r >= 0) { c = cnext; cnext = r >= 1 ? seq[r - 1] : 4; }
 			if (r < 0) {
 				if (dbgD) { /* D[readLen] (inexact_match.c:249-250) */
 					int32_t *dst = phase ? dbgDs + ((size_t)rid * dbg_lds + plen) * 2 : dbgD + ((size_t)rid * dbg_ld + plen) * 2;
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				if (phase == 0 && kp.seed_length && len > kp.seed_length) { /* inexact_match.c:141-143 */
 					phase = 1; plen = kp.seed_length; r = plen - 1; z = 0; prev_nm = 0; prev_byte = 0;
 					cL = 0; cU = last_row; curT = 1;
+					c = seq[r]; cnext = r >= 1 ? seq[r - 1] : 4;
 				} else {
 					b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = (uint8_t)(cntN > 255 ? 255 : cntN);
 					*(uint32_t *)(b.dbuf + (size_t)rid * b.dstride + b.dstride - 8) = r_vis; /* work done for this read: a cheap predictor of search cost */
@@ -750,8 +752,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
-	int e_score = 0;
+#define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
+	uint32_t rec_x = 0, rec_y = 0; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
 	uint32_t n_bkt = 0, n_est = 0, n_eld = 0, n_rec = 0; /* wave-uniform: buckets fetched, heap entries stored / loaded, per-position records loaded */
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		exact_mode = ((fl >> 1) & 1u) != 0; cursel = ((fl >> 2) & 1u) != 0; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
 		myslot = (fl >> 8) & 0xFFu;
 		rid = a0.y;
-		len = (int)(a0.z & 255u); best_score = (int)((a0.z >> 8) & 255u); max_diff = (int)((a0.z >> 16) & 255u); e_score = (int)(a0.z >> 24);
+		len = (int)(a0.z & 255u); best_score = (int)((a0.z >> 8) & 255u); max_diff = (int)((a0.z >> 16) & 255u);
 		num_best = (int)a0.w;
 		n_alns = (int)a1.x; r = (int)a1.y; s = (int)a1.z; curT = (int)a1.w;
 		nx.T = (int)a2.y; cL = p64(a2.z, a2.w);
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		nxw = mysave[14].x;
 		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
+		rec_ok = false;
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	} else {
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const bool unrep = len == BAD_LEN;
 				if (unrep) len = 0;
 				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
-				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
+				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride); rec_ok = false;
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
 				n_alns = 0; exact_mode = false; active = true;
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				auto hi = [](P v) { return (uint32_t)((uint64_t)v >> 32); };
 				const uint32_t fl = 1u | ((exact_mode ? 1u : 0u) << 1) | ((cursel ? 1u : 0u) << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
 				                    ((h.top_valid ? 1u : 0u) << 5) | (myslot << 8);
-				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)best_score << 8) | ((uint32_t)max_diff << 16) | ((uint32_t)e_score << 24), (uint32_t)num_best);
+				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)best_score << 8) | ((uint32_t)max_diff << 16), (uint32_t)num_best);
 				mysave[1] = make_uint4((uint32_t)n_alns, (uint32_t)r, (uint32_t)s, (uint32_t)curT);
 				mysave[2] = make_uint4(0u, (uint32_t)nx.T, lo(cL), hi(cL));
 				mysave[3] = make_uint4(lo(cU), hi(cU), lo(nx.tL), hi(nx.tL));
@@ -939,7 +943,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				h_mirror = h.top_valid;
 #endif
 				h.pop(e); /* heap_pop :594-610: the top of the best bucket, usually straight from its register mirror */
-				e_score = bk;
 				is_group = (e.sa & 3u) == (uint32_t)STATE_GROUP;
 				/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the
 				 * group's last child, which happens in the next iteration, once the children are in place */
@@ -987,10 +990,15 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
 		if (need_rank || (from_pop && len < kp.seed_length)) { /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
-			n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(true))));
-			const uint2 rec = recs[widx]; /* one load: D[i-1], D[i-2] | D_seed pair | seq[len - widx] */
-			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
-			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
+			if (!exact_mode) rec_ok = false; /* (a popped entry has its own position) */
+			if (!rec_ok) { /* (every interval of a multi-interval exact step reads the same record: one step in four at GRCh37 scale) */
+				n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(true))));
+				const uint2 rec = recs[widx]; /* one load: D[i-1], D[i-2] | D_seed pair | seq[len - widx] */
+				rec_x = rec.x; rec_y = rec.y;
+			}
+			rec_ok = exact_mode; /* (cleared again when the step's last interval is done) */
+			wd = rec_x & 0xFFFFu; ws = rec_x >> 16;
+			const int cf = (int)(rec_y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
 			const P pl = (P)(iL - 1);
 			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
@@ -1214,7 +1222,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				s++;
 				if (!ovf && s >= curT) {
 					cursel = !cursel; curT = nx.T; cL = nx.tL; cU = nx.tU;
-					nx.T = 0; s = 0;
+					nx.T = 0; s = 0; rec_ok = false;
 					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < (seeding ? len - PRECALC_LEN : 0)) exact_done = true; }
@@ -1350,6 +1358,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #undef lbase
 #undef myalns
 #undef mysave
+#undef e_score
 
 /* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_gather, L rows
  * only) and every lane ranks all 15 codes of its own bucket from LDS (block_pops): the access pattern and the ALU work of a rank

@@ -59,7 +59,7 @@ static void retire(worker_t *w, bwb_hip_ctx *ctx, int slot, size_t c) {
 	atomic_store(&cr->ready, 1);
 }
 
-/* One host thread per GPU.  Chunks are streamed through three slots of the context: while the search slice of chunk j runs,
+/* One host thread per GPU.  Chunks are streamed through the slots of the context: while the search slice of chunk j runs,
  * chunk j+1 is already uploaded and queued behind it and the hits of chunk j-1 are on their way back; a slice parks its
  * unfinished reads for the next one instead of draining (include/bwbble_hip.h), so the GPU never runs a batch's tail alone. */
 static void *gpu_worker(void *arg) {
@@ -70,7 +70,8 @@ static void *gpu_worker(void *arg) {
 	const bwtint_t hdr[5] = { w->BWT->length, w->BWT->num_words, w->BWT->num_sa, w->BWT->num_occ, w->BWT->sa0_index };
 	if (bwb_hip_ctx_create(w->device, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, &ctx)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
 	if (dbg) { fprintf(stderr, "[bwb host] worker %d (device %d): context + index upload %.3f s\n", w->gpu, w->device, wall() - tq); tq = wall(); }
-	enum { NS = 3 };
+	enum { NS = BWB_MAX_SLOTS }; /* chunks in flight: the heaviest reads of a chunk take several slices' time (they are parked and resumed), and
+	                                a slot can be uploaded again only when its chunk is complete */
 	size_t in_slot[NS];
 	size_t j = 0; /* chunks this worker has submitted */
 	for (;;) {
@@ -89,10 +90,10 @@ static void *gpu_worker(void *arg) {
 			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
 		in_slot[slot] = c;
 		j++;
-		if (j >= 3) retire(w, ctx, (int)((j - 3) % NS), in_slot[(j - 3) % NS]); /* two slices stay queued while the host waits */
+		if (j >= NS) retire(w, ctx, (int)((j - NS) % NS), in_slot[(j - NS) % NS]); /* NS - 1 slices stay queued while the host waits */
 		if (dbg) { fprintf(stderr, "[bwb host] worker %d: chunk %zu (%u reads) submitted at +%.3f s\n", w->gpu, c, n, wall() - tq); }
 	}
-	for (size_t k = j >= 2 ? j - 2 : 0; k < j; k++) retire(w, ctx, (int)(k % NS), in_slot[k % NS]);
+	for (size_t k = j >= NS - 1 ? j - (NS - 1) : 0; k < j; k++) retire(w, ctx, (int)(k % NS), in_slot[k % NS]);
 	bwb_stats st;
 	if (bwb_hip_flush(ctx) || bwb_hip_get_stats(ctx, &st)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
 	w->total = st;

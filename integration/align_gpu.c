@@ -31,7 +31,7 @@ SAME_FIELD(matched_Ncontig); SAME_FIELD(use_precalc); SAME_FIELD(is_multiref); S
 _Static_assert(sizeof(bwtint_t) == sizeof(uint64_t), "bwtint_t must be 64-bit (bwt.h)");
 
 #define GPU_BATCH (1u << 21)  /* reads per GPU batch; the reference's READ_BATCH_SIZE (align.h:14) only paces its output */
-#define GPU_SLOTS 3
+#define GPU_SLOTS BWB_MAX_SLOTS
 
 static void gpu_die(const char *what) {
 	printf("align_reads_inexact_gpu: %s: %s\n", what, bwb_hip_last_error());
