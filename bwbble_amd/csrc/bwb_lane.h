@@ -358,6 +358,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	bool active = false, done = false;
 	uint32_t rid = 0;
 	int len = 0, phase = 0, plen = 0, r = 0, z = 0, s = 0, curT = 0, cursel = 0;
+	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* the interval of the next iteration, when it comes from the list in memory */
 	int c = 4, cnext = 4; /* seq[r] and seq[r - 1]: loaded once per position, one position ahead (round 2 loaded seq[r] in every iteration) */
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				seq = b.reads + (size_t)rid * b.stride;
 				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
 				c = len > 0 ? seq[len - 1] : 4; cnext = len > 1 ? seq[len - 2] : 4;
-				cL = 0; cU = last_row; curT = 1;
+				cL = 0; cU = last_row; curT = 1; nxi_valid = false;
 				nx.T = 0;
 				active = len > 0;
 				if (!(kp.seed_length && len > kp.seed_length)) {
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			if (c > 3 && phase == 0) cntN++;
 			if (c <= 3) {
 				if (s == curT - 1) { iL = cL; iU = cU; }
+				else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous iteration */
 				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
 			}
 		}
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 		KidCtx<P> kc;
 		uint32_t ne = wave_children<P>(buckets, last_row, need, iL, iU, false, sb, stage, zero_row, lane, nbk, kc); /* every lane of the wave loads */
 		n_bkt += nbk;
-		if (!active) continue;
+		if (!active) { nxi_valid = false; continue; }
 		bool ovf = false;
 		if (c <= 3) {
 			r_vis += (pi_regular(last_row, (P)(iL - 1)) ? 1 : 0) + (pi_regular(last_row, iU) ? 1 : 0);
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			}
 			s++;
 		}
-		if (ovf) { b.status[rid] = ST_D_OVF; active = false; continue; }
+		if (ovf) { b.status[rid] = ST_D_OVF; active = false; nxi_valid = false; continue; }
 		if (c > 3 || s >= curT) {
 			/* position finished: swap lists (inexact_match.c:234-237) */
 			cursel ^= 1;
@@ -470,6 +472,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				}
 			}
 		}
+		/* the interval of the next iteration, when it is not the list's tail (which is in registers): on its way now */
+		nxi_valid = active && c <= 3 && s != curT - 1;
+		if (nxi_valid) nxi = (lbase + cursel * cap)[s];
 	}
 	if (vis) { atomicAdd(&stats[STAT_VIS_SINGLE], vis); atomicAdd(&stats[STAT_VIS_CALCD], vis); }
 	if (lane == 0 && n_bkt) atomicAdd(&stats[STAT_BKT_CALCD], (unsigned long long)n_bkt);
