@@ -306,28 +306,32 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	ScratchClass &s = c->cls[k];
 	uint32_t blocks, lcap, acap;
 	if (k == 0) {
-		/* 3 blocks (12 waves) per CU for both kernels: what their register and LDS budgets are built for (bwb_lane.h) */
-		if (!s.ready) {
-			c->bpc_search = LANE_WAVES_PER_SIMD; c->bpc_calcd = LANE_WAVES_PER_SIMD;
+		/* Blocks (of four waves) per CU.  Both kernels are built for three (bwb_lane.h).  kl_search runs two when the parameters allow
+		 * more than three differences: every lane holds a read with its heap, and the stationary heap population of 196 608 reads
+		 * with -n 5 on 150 bp reads exceeds the 200 GB chunk pool (reads are then abandoned and re-run: 65 k reads/s against 122 k
+		 * with two blocks, profiles/r3_c5_variants.txt); with -n 3 the pool is 62 % full at three.  The choice can change only
+		 * while nothing is parked (the grid, and with it the pool geometry, is fixed for the life of a stream). */
+		if (!s.ready || !c->parked) {
+			c->bpc_search = c->kp.max_diff > 3 ? std::min(2, LANE_WAVES_PER_SIMD) : LANE_WAVES_PER_SIMD;
+			c->bpc_calcd = LANE_WAVES_PER_SIMD;
 			if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
 			if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
 			if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
 			/* A slice's blocks must all be resident at once: a parked read only moves while its block runs, and a block that had to
 			 * wait for another one to leave would find the cursor exhausted and park again at once.  So never more blocks per CU than
 			 * the runtime says fit (registers, LDS). */
-			{
-				int occ = 0;
-				const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true> : (const void *)kl_search<uint32_t, false>)
-				                          : (c->wide ? (const void *)kl_search<uint64_t, true> : (const void *)kl_search<uint64_t, false>);
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
-					if (c->dbg || occ < c->bpc_search) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU (asked for %d)\n", occ, LANE_BLOCK, c->bpc_search);
-					c->bpc_search = std::min(c->bpc_search, occ);
-				}
-				const void *kd = c->pos32 ? (const void *)kl_calc_d<uint32_t> : (const void *)kl_calc_d<uint64_t>;
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) c->bpc_calcd = std::min(c->bpc_calcd, occ);
+			int occ = 0;
+			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true> : (const void *)kl_search<uint32_t, false>)
+			                          : (c->wide ? (const void *)kl_search<uint64_t, true> : (const void *)kl_search<uint64_t, false>);
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
+				if (c->dbg && !s.ready) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU\n", occ, LANE_BLOCK);
+				c->bpc_search = std::min(c->bpc_search, occ);
 			}
+			const void *kd = c->pos32 ? (const void *)kl_calc_d<uint32_t> : (const void *)kl_calc_d<uint64_t>;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) c->bpc_calcd = std::min(c->bpc_calcd, occ);
 		}
-		blocks = (uint32_t)(c->num_cu * std::max(c->bpc_search, c->bpc_calcd)); lcap = 4096; acap = 256;
+		/* (the scratch is sized for the larger grid: the two kernels share it) */
+		blocks = (uint32_t)(c->num_cu * std::max(LANE_WAVES_PER_SIMD, std::max(c->bpc_search, c->bpc_calcd))); lcap = 4096; acap = 256;
 	} else if (k == 1) {
 		blocks = (uint32_t)std::max(1, c->num_cu / 2); lcap = 8192; acap = 1024;
 	} else {

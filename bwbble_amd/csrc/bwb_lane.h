@@ -170,26 +170,27 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	__builtin_amdgcn_wave_barrier();
 }
 
-/* acc[] += #j among the characters [lo, hi] of the block whose planes are in `row` (slices 4-7, slice k at row[(k + rot) & 7]) for
- * the eight codes j = 8 HALF .. 8 HALF + 7; acc[2 s + t] <-> code 8 HALF + 2 s + t, which is component 2 HALF + t of count slice s.
- * `first` = code of the block's first character (bwt.c:780).  One sub-block at a time: 4 plane words live. */
-template <int HALF>
-__device__ __forceinline__ void block_pops(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[8], uint32_t &first) {
+/* acc[] += #j among the characters [lo, hi] of the block whose planes are in `row` (slices 4-7, slice k at row[(k + rot) & 7]), j = 1..15:
+ * acc[j] for j < 8 is component (j & 1) of count slice j >> 1, acc[8 + c] (code 8 + c) component 2 + (c & 1) of slice c >> 1.
+ * `first` = code of the block's first character (bwt.c:780).  One sub-block at a time, the next one's planes on their way: 8 plane
+ * words live, not the 32 of the bucket. */
+__device__ __forceinline__ void block_pops16(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[16], uint32_t &first) {
 	u32x4 p = row[(4 + rot) & 7];
 	first = (p.x & 1u) | ((p.y & 1u) << 1) | ((p.z & 1u) << 2) | ((p.w & 1u) << 3);
 #pragma unroll
 	for (int w = 0; w < 4; w++) {
 		u32x4 pn = p;
-		if (w < 3) pn = row[(4 + w + 1 + rot) & 7]; /* the next sub-block's planes are on their way while this one is counted */
-		const int nh = hi + 1 - 32 * w, nl = lo - 32 * w; /* characters [0, nh) minus [0, nl) of this sub-block */
+		if (w < 3) pn = row[(4 + w + 1 + rot) & 7];
+		const int nh = hi + 1 - 32 * w, nl = lo - 32 * w;
 		const uint32_t mh = nh <= 0 ? 0u : (nh >= 32 ? 0xFFFFFFFFu : ((1u << nh) - 1u));
 		const uint32_t ml = nl <= 0 ? 0u : (nl >= 32 ? 0xFFFFFFFFu : ((1u << nl) - 1u));
-		const uint32_t m = mh & ~ml & (HALF ? p.w : ~p.w);   /* bit 3 of the code */
+		const uint32_t m = mh & ~ml;
 		const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
-		const uint32_t b[2] = { m & ~p.z, m & p.z };
+		const uint32_t m2 = m & ~p.z, m2p = m & p.z;
+		const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
 #pragma unroll
-		for (int c = 0; c < 8; c++) acc[c] += __popc(a[c & 3] & b[c >> 2]);
-		__builtin_amdgcn_sched_barrier(0); /* (keeps the four sub-blocks apart: interleaved they need 4 x the registers) */
+		for (int c = 1; c < 16; c++) acc[(c & 7) + 8 * (c >> 3)] += __popc(a[c & 3] & b[c >> 2]);
+		__builtin_amdgcn_sched_barrier(0);
 		p = pn;
 	}
 }
@@ -239,11 +240,11 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 		const bool have = pi.blkL != NONE32;
 		const Lds<u32x4> src = have ? own : zero_row;
 		const int srot = have ? rot : 0;
-		uint32_t fL = 0, a0[8], a1[8];
+		uint32_t fL = 0, a01[16];
 #pragma unroll
-		for (int c = 0; c < 8; c++) a0[c] = a1[c] = 0;
-		block_pops<0>(src, srot, 0, pi.offL, a0, fL);
-		block_pops<1>(src, srot, 0, pi.offL, a1, fL);
+		for (int c = 0; c < 16; c++) a01[c] = 0;
+		block_pops16(src, srot, 0, pi.offL, a01, fL);
+		uint32_t *a0 = a01, *a1 = a01 + 8;
 #pragma unroll
 		for (int s = 0; s < 4; s++) {
 			u32x4 q = src[(s + srot) & 7];
@@ -270,11 +271,11 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 			const Lds<u32x4> src = fetched ? stage + 512 + k * 8 : (pi.same ? own : zero_row);
 			const int srot = fetched ? (int)((k >> 1) & 7) : (pi.same ? rot : 0);
 			const int lo = pi.same ? pi.offL + 1 : 0;
-			uint32_t fU = 0, a0[8], a1[8];
+			uint32_t fU = 0, a01[16];
 #pragma unroll
-			for (int c = 0; c < 8; c++) a0[c] = a1[c] = 0;
-			block_pops<0>(src, srot, lo, pi.offU, a0, fU);
-			block_pops<1>(src, srot, lo, pi.offU, a1, fU); /* (the own row's planes are read before relU overwrites them) */
+			for (int c = 0; c < 16; c++) a01[c] = 0;
+			block_pops16(src, srot, lo, pi.offU, a01, fU); /* (the own row's planes are read before relU overwrites them) */
+			uint32_t *a0 = a01, *a1 = a01 + 8;
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
 				u32x4 q = src[(s + srot) & 7];          /* same bucket: relL (written above); else the U bucket's counts */
@@ -1394,8 +1395,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		const bool own = pi.blkL != NONE32;
 		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
 		const int rot = own ? (lane >> 1) & 7 : 0;
-		block_pops<0>(row, rot, 0, pi.offL, rel, first);
-		block_pops<1>(row, rot, 0, pi.offL, rel + 8, first);
+		block_pops16(row, rot, 0, pi.offL, rel, first);
 #pragma unroll
 		for (int s = 0; s < 4; s++) { const u32x4 c4 = row[(s + rot) & 7]; rel[2 * s] += c4.x; rel[2 * s + 1] += c4.y; rel[8 + 2 * s] += c4.z; rel[8 + 2 * s + 1] += c4.w; }
 		if (q < n) {
