@@ -648,10 +648,18 @@ template <typename P, bool WIDE> struct LHeap {
 	}
 };
 
+/* sum over the wave of a small per-lane count (< 32), as a wave-uniform value: five ballots (the lanes must have converged) */
+__device__ __forceinline__ uint32_t wave_sum5(uint32_t v) {
+	uint32_t t = 0;
+#pragma unroll
+	for (int b = 0; b < 5; b++) t += (uint32_t)__popcll(__ballot((v >> b) & 1u)) << b;
+	return t;
+}
+
 /* stores one heap entry at p and advances p */
 template <typename P, bool WIDE>
 __device__ __forceinline__ void emit_entry(uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs, uint32_t &n_st) {
-	n_st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_st + (uint32_t)__popcll(__ballot(true)))); /* (wave-uniform, kept in a scalar register: entries stored by the lanes that are here) */
+	n_st++; /* (per lane and iteration; summed over the wave where the lanes meet again: wave_sum5) */
 	L = pos_enc<P>(L); U = pos_enc<P>(U);
 	if (WIDE) {
 		p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
@@ -995,10 +1003,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		int cr = 4, nvis = 0;
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
-		if (need_rank || (from_pop && len < kp.seed_length)) { /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
+		const bool want_rec = need_rank || (from_pop && len < kp.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
+		n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(want_rec && !(exact_mode && rec_ok)))));
+		if (want_rec) {
 			if (!exact_mode) rec_ok = false; /* (a popped entry has its own position) */
 			if (!rec_ok) { /* (every interval of a multi-interval exact step reads the same record: one step in four at GRCh37 scale) */
-				n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(true))));
 				const uint2 rec = recs[widx]; /* one load: D[i-1], D[i-2] | D_seed pair | seq[len - widx] */
 				rec_x = rec.x; rec_y = rec.y;
 			}
@@ -1029,6 +1038,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
 		if (!kp.multiref) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
+		uint32_t st_cnt = 0; /* heap entries this lane stores in this iteration */
 		auto kid = [&](int j, P &L, P &U) { kid_get<P>(kc, sb, kp.multiref ? j : (int)((0x173Fu >> (4 * (j - 1))) & 15u), L, U); };
 		STAMP(3);
 
@@ -1047,7 +1057,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const int j = __ffs((int)gm) - 1;
 					gm &= gm - 1;
 					kid(j, h.top.L, h.top.U);
-					if (gm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, e.f, sd, eruns, n_est); /* (the last child is popped next: the register mirror is its only copy) */
+					if (gm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, e.f, sd, eruns, st_cnt); /* (the last child is popped next: the register mirror is its only copy) */
 				}
 				h.top.f = e.f; h.top.sa = sd; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi;
 				h.cst = st0 + (uint32_t)n; h.mark(e_score); h.top_valid = true;
@@ -1155,10 +1165,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
 						   * holds the parent's interval (a single deletion child is stored as itself) */
 							uint4 *pg = tG == 0 ? p0 : (tG == 1 ? p1 : p2);
-							if (nIns) emit_entry<P, WIDE>(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, n_est);
+							if (nIns) emit_entry<P, WIDE>(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, st_cnt);
 							const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
-							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit_entry<P, WIDE>(pg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, n_est); }
-							else if (nDel) emit_entry<P, WIDE>(pg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, n_est);
+							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit_entry<P, WIDE>(pg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, st_cnt); }
+							else if (nDel) emit_entry<P, WIDE>(pg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, st_cnt);
 							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
 						}
 						STAMP(12);
@@ -1171,7 +1181,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								xm &= xm - 1;
 								P cl, cu;
 								kid(j, cl, cu);
-								emit_entry<P, WIDE>(px, cl, cu, f_mis, sm, eruns, n_est);
+								emit_entry<P, WIDE>(px, cl, cu, f_mis, sm, eruns, st_cnt);
 							}
 							if (tX == 1) p1 = px; else p0 = px;
 							uint32_t mm = matchm;
@@ -1181,7 +1191,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								kid(j, h.top.L, h.top.U);
 								/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket
 								 * being popped): the register mirror is its only copy, its slot is reserved but never written. */
-								if (mm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, f_match, sm, eruns, n_est);
+								if (mm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, f_match, sm, eruns, st_cnt);
 							}
 							if (matchm) { h.top.f = f_match; h.top.sa = sm; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi; top_ok = true; }
 						} else { /* mm_score == 0: one bucket, interleaved in code order */
@@ -1191,7 +1201,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								am &= am - 1;
 								P cl, cu;
 								kid(j, cl, cu);
-								emit_entry<P, WIDE>(p0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns, n_est);
+								emit_entry<P, WIDE>(p0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns, st_cnt);
 							}
 						}
 						STAMP(13);
@@ -1293,8 +1303,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 		STAMP(15);
 		HIST(H_TOP_RELOAD, active && !h.top_valid && h.cst != NONE32);
-		if (active && !h.top_valid && h.cst != NONE32) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
-			n_eld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_eld + (uint32_t)__popcll(__ballot(true))));
+		const bool reload = active && !h.top_valid && h.cst != NONE32;
+		n_eld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_eld + (uint32_t)__popcll(__ballot(reload))));
+		n_est = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_est + wave_sum5(st_cnt > 31u ? 31u : st_cnt)));
+		if (reload) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
 			h.load_entry(h.cst, h.top);
 			h.top_valid = true;
 		}
