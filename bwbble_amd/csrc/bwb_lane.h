@@ -1032,8 +1032,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		uint32_t stX = NONE32, stG = NONE32;
 		if (from_pop) { /* the side heap buckets' states, on their way while the entry is examined (clamped: an entry near the top score is
 		                   never expanded, but the load is unconditional).  Issued after the rank: two registers less across it. */
+#ifndef BWB_COND_BSTATE
 			stX = h.bstate[scX < nb ? scX : nb - 1];
 			stG = h.bstate[scG < nb ? scG : nb - 1];
+#endif
 		}
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
@@ -1138,6 +1140,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const int k2 = tG == 2 ? nG : 0;
 					STAMP(9);
 					uint32_t st0 = h.reserve(h.cst, k0, ovf);
+#ifdef BWB_COND_BSTATE /* experiment: fetch the side buckets' states only when the expansion pushes to them (8 % / 31 % of the expansions) */
+					if (k1 > 0) stX = h.bstate[scX];
+					if (k2 > 0) stG = h.bstate[scG];
+#endif
 					uint32_t st1 = h.reserve(stX, k1, ovf);
 					uint32_t st2 = h.reserve(stG, k2, ovf);
 					STAMP(10);
