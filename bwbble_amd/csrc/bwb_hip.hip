@@ -342,10 +342,10 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
 	const uint32_t brow = std::max<uint32_t>(BSTATE_ROW_MIN, ((uint32_t)c->kp.num_buckets + 63u) & ~63u);
 	const size_t b_bstate = al((size_t)brow * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
-	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16);
+	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16), b_recs = al((size_t)nslots * LANE_RECS * 8);
 	/* class 0 runs kl_calc_d of the next batch while parked reads keep their lists: it gets a second set; the re-run classes
 	 * are drained before anything else uses them */
-	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_save + b_bsave;
+	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_recs + b_save + b_bsave;
 	if (!(s.mem.p && s.mem.bytes >= bytes)) {
 		if (k == 0 && c->parked) return fail(BWB_E_STATE, "the class-0 scratch cannot grow while reads are parked (flush first)");
 		s.mem.release();
@@ -361,10 +361,10 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.lists_d = s.sc.lists;
 	if (k == 0) { s.sc.lists_d = (void *)base; base += b_lists; }
 	s.sc.alns = (uint4 *)base; base += b_alns;
+	s.sc.winfo = (uint2 *)base; base += b_recs;
 	s.sc.save = (uint4 *)base; base += b_save;
 	s.sc.blocksave = (uint32_t *)base;
-	s.sc.winfo = nullptr;
-	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = 0; s.sc.brow = brow;
+	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = LANE_RECS; s.sc.brow = brow;
 	s.sc.keep = c->keep;
 	s.blocks = blocks;
 	s.ready = true;

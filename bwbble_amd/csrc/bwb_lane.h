@@ -47,6 +47,7 @@ template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 #define SAVE_U4 16               /* uint4 per lane in the save area */
+#define LANE_RECS 258            /* 8-byte per-position records per lane: positions 0 .. 256 + 1 of a read of at most 255 bases */
 
 struct LaneScratch {
 	uint4 *pool;                /* chunk pool in POOL_REGIONS regions (block b uses region b % n_regions: its XCD's when all 8 are in use):
@@ -63,7 +64,8 @@ struct LaneScratch {
 	uint4 *save;                /* [nslots][SAVE_U4]: a lane's read, parked at the end of a slice (word 0 bit 0 = occupied) */
 	uint32_t *blocksave;        /* [blocks][4]: a block's recycle stack {~head lo, ~head hi, chunks, -} across slices */
 	uint4 *alns;                /* [nslots][acap*2] */
-	uint2 *winfo;               /* [nslots][wstride] */
+	uint2 *winfo;               /* [nslots][wstride]: the per-position records of the read a lane is working on (copied from the slot's
+	                               buffer when the read starts: kl_search) */
 	uint32_t nslots, lcap, acap, wstride;
 	uint32_t brow;              /* bucket states per lane */
 };
@@ -737,6 +739,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
 #define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
 #define mysave (sc.save + (size_t)slotv * SAVE_U4)
+	/* The read's per-position records {D pair, D_seed pair, base} (kl_calc_d wrote them into the slot's buffer) are copied into the lane's
+	 * scratch when the read starts: the one load per iteration then goes to a page the whole block shares, instead of 64 different 2 MB
+	 * pages of an 16 GB region per wave instruction (the shape that address translation, not HBM, bounds: DESIGN.md section 2.2). */
+#ifndef BWB_NO_LOCAL_RECS
+#define recs ((const uint2 *)(sc.winfo + (size_t)slotv * sc.wstride))
+#endif
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
@@ -767,7 +775,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 #define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
+#ifdef BWB_NO_LOCAL_RECS
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
+#endif
 	uint32_t rec_x = 0, rec_y = 0; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
@@ -806,7 +816,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z;
 		nxw = mysave[14].x;
 		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
+#ifdef BWB_NO_LOCAL_RECS
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
+#endif
 		rec_ok = false;
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -849,7 +861,16 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const bool unrep = len == BAD_LEN;
 				if (unrep) len = 0;
 				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
-				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride); rec_ok = false;
+#ifdef BWB_NO_LOCAL_RECS
+				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
+#else
+				{
+					const uint2 *src = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
+					uint2 *dst = sc.winfo + (size_t)slotv * sc.wstride;
+					for (int i = 0; i <= len + 1; i++) dst[i] = src[i];
+				}
+#endif
+				rec_ok = false;
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
 				n_alns = 0; exact_mode = false; active = true;
@@ -1383,6 +1404,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #undef myalns
 #undef mysave
 #undef e_score
+#ifndef BWB_NO_LOCAL_RECS
+#undef recs
+#endif
 
 /* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_gather, L rows
  * only) and every lane ranks all 15 codes of its own bucket from LDS (block_pops): the access pattern and the ALU work of a rank
