@@ -108,3 +108,20 @@ def test_unsupported_parameters_fail_loudly(toy_ctx):
         toy_ctx.align(bw.params(["-n", "200"]), seqs, lens)
     with pytest.raises(bw.BwbError):  # result of a slot that was never submitted
         toy_ctx.slot_result(3)
+
+
+def test_penalty_and_score_range_limits(toy_ctx, oracle, golden):
+    """Score ranges beyond round 2's 128 heap buckets work (bucket-state rows are sized by the range: here (n+1) M + 2 O + 7 E = 320
+    buckets) and equal the oracle; a penalty above 63 is refused (the non-empty buckets are a 64-bit window above the current one)."""
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "toy.fq"), max_reads=300))
+    flags = ["-n", "3", "-M", "40", "-O", "45", "-E", "10"]
+    off, alns = toy_ctx.align(bw.params(flags), seqs, lens)
+    idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"))
+    want, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags))
+    assert bw.aln_bytes(off, alns) == want
+    st = toy_ctx.stats()
+    assert st.heap_pops == ost.heap_pops and st.heap_pushes == ost.heap_pushes
+    for bad in (["-M", "64"], ["-O", "70"], ["-E", "100"], ["-n", "100", "-M", "60"]):
+        with pytest.raises(bw.BwbError):
+            toy_ctx.align(bw.params(bad), seqs[:1], lens[:1])
+    toy_ctx.align(bw.params(["-n", "2"]), seqs[:50], lens[:50])  # the context is still usable
