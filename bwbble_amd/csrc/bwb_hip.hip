@@ -254,6 +254,11 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 	delete c;
 }
 
+#ifdef BWB_LOCAL_RECS
+#define LOCAL_RECS_BUILD 1
+#else
+#define LOCAL_RECS_BUILD 0
+#endif
 static size_t lane_lds(const bwb_hip_ctx *c) {
 	(void)c;
 	return (size_t)LDS_WAVES_OFF + (size_t)(LANE_BLOCK / 64) * WAVE_LDS_BYTES; /* base table + zero row + per wave: gather staging / children */
@@ -342,7 +347,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
 	const uint32_t brow = std::max<uint32_t>(BSTATE_ROW_MIN, ((uint32_t)c->kp.num_buckets + 63u) & ~63u);
 	const size_t b_bstate = al((size_t)brow * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
-	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16), b_recs = al((size_t)nslots * LANE_RECS * 8);
+	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16), b_recs = al((size_t)nslots * LANE_RECS * 8) * LOCAL_RECS_BUILD;
 	/* class 0 runs kl_calc_d of the next batch while parked reads keep their lists: it gets a second set; the re-run classes
 	 * are drained before anything else uses them */
 	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_recs + b_save + b_bsave;

@@ -739,10 +739,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
 #define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
 #define mysave (sc.save + (size_t)slotv * SAVE_U4)
-	/* The read's per-position records {D pair, D_seed pair, base} (kl_calc_d wrote them into the slot's buffer) are copied into the lane's
-	 * scratch when the read starts: the one load per iteration then goes to a page the whole block shares, instead of 64 different 2 MB
-	 * pages of an 16 GB region per wave instruction (the shape that address translation, not HBM, bounds: DESIGN.md section 2.2). */
-#ifndef BWB_NO_LOCAL_RECS
+	/* Experiment kept as a build option (make exp X=localrecs XFLAGS=-DBWB_LOCAL_RECS): the read's per-position records {D pair, D_seed pair,
+	 * base} copied from the slot's buffer into the lane's scratch when the read starts, so that the one record load per iteration goes to a
+	 * page the whole block shares instead of 64 different 2 MB pages of a 16 GB region per wave instruction.  Measured at GRCh37 scale:
+	 * 267.4 k against 270.3 k reads/s without it (tools/r3_s10.sh) - the record load is not what the gather waits for.  Off. */
+#ifdef BWB_LOCAL_RECS
 #define recs ((const uint2 *)(sc.winfo + (size_t)slotv * sc.wstride))
 #endif
 	const int lcap = (int)sc.lcap;
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 #define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
-#ifdef BWB_NO_LOCAL_RECS
+#ifndef BWB_LOCAL_RECS
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
 #endif
 	uint32_t rec_x = 0, rec_y = 0; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z;
 		nxw = mysave[14].x;
 		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
-#ifdef BWB_NO_LOCAL_RECS
+#ifndef BWB_LOCAL_RECS
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
 #endif
 		rec_ok = false;
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const bool unrep = len == BAD_LEN;
 				if (unrep) len = 0;
 				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
-#ifdef BWB_NO_LOCAL_RECS
+#ifndef BWB_LOCAL_RECS
 				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
 #else
 				{
@@ -1402,7 +1403,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #undef myalns
 #undef mysave
 #undef e_score
-#ifndef BWB_NO_LOCAL_RECS
+#ifdef BWB_LOCAL_RECS
 #undef recs
 #endif
 
