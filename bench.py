@@ -169,12 +169,12 @@ def main():
     t0 = time.perf_counter()
     run_steps(a.steps)  # ends with a flush: the library's streams are idle when it returns
     torch.cuda.synchronize() if torch.cuda.is_available() else None
+    dt_rank = time.perf_counter() - t0  # this rank's own time for its K steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     st = ctx.stats()
     kern_ms = st.ms_calc_d + st.ms_search
     visits = st.visits_single + st.visits_alphabet
-    dt_rank = dt
     dt, kern_ms, visits_all = grp.reduce_step(dt, kern_ms, float(visits))  # MAX time over ranks, SUM of visits
     rank_rates = [v[0] for v in grp.all_gather_pairs(int(a.reads * a.steps / dt_rank), 0)]  # every rank's own reads/s (its own clock between the barriers)
     off0, alns0 = ctx.slot_result(0)  # hits of batch 0 = the first B reads of this shard
