@@ -289,9 +289,10 @@ def measured_traffic(a, B, dom_name, dom):
             continue
         if pj.get("source_hash") != source_hash():
             return None, f"{os.path.relpath(prof, ROOT)} was measured on other kernel sources (hash {pj.get('source_hash')}, now {source_hash()}): not quoted"
-        return (pj[dom_name]["hbm_bytes_per_launch"],
+        # (the profile's own passes have fewer steps per draining launch than this run: scale its bytes per STEP to this run's launches)
+        return (pj[dom_name]["hbm_bytes_per_step"] * a.steps / max(dom["launches"], 1),
                 f"{os.path.relpath(prof, ROOT)}: separate rocprofv3 --pmc passes of this command on this kernel source (hash {pj['source_hash']}); "
-                f"{pj.get('method', '')}; NOT measured in this run")
+                f"{pj.get('method', '')}; bytes per step there x steps / launches here; NOT measured in this run")
     return None, "not measured in this run (PMC counters need rocprofv3 passes: tools/pmc_traffic.sh) and no stored profile of this workload"
 
 
