@@ -31,8 +31,22 @@
 #define BWB_ROW_END (BWB_NSB_MAX + 1)   /* base row for position length-1: C[j+1] (bwt.c:375-392) */
 #define BWB_BASE_ROWS (BWB_NSB_MAX + 2)
 
+/* EXPERIMENT (-DBWB_BKT64): the one-read-per-lane kernels rank from a second copy of the index with 64 characters per 128-byte
+ * bucket: slices 0-3 the counts before the bucket (as above), slices 4-5 the planes of its two 32-character sub-blocks, slice 6
+ * the counts INSIDE the first sub-block as bytes (component s = {mid[2s], mid[2s+1], mid[2s+8], mid[2s+9]}), slice 7.x the code of
+ * the first character of the enclosing 128-character block (O_alphabet's quirk, bwt.c:780).  A rank is then counts + (second
+ * sub-block ? mid : 0) + ONE masked pass over one sub-block instead of four: 2 bytes of index per character instead of 1. */
+#ifdef BWB_BKT64
+#define BKT_SHIFT 6
+#else
+#define BKT_SHIFT 7
+#endif
+#define BKT_MASK ((1 << BKT_SHIFT) - 1)
+#define BKT_SB_SHIFT (BWB_SB_SHIFT + 7 - BKT_SHIFT) /* buckets per superblock: 2^31 characters either way */
+
 struct DevIndex {
 	const uint4 *buckets;               /* nblk * 8 slices */
+	const uint4 *buckets64;             /* -DBWB_BKT64: 2 * nblk * 8 slices, else null */
 	uint64_t length;                    /* n + 1 (bwt_t.length) */
 	uint64_t nblk;
 	uint64_t base[BWB_BASE_ROWS][16];

@@ -116,7 +116,7 @@ struct bwb_hip_ctx {
 	int device = 0, num_cu = 0;
 	hipStream_t stream = nullptr, cstream = nullptr, rstream = nullptr; /* kernels; uploads; results */
 	DevIndex ix{};
-	DevMem d_buckets, d_SA, d_stats, d_descs, d_misc;
+	DevMem d_buckets, d_buckets64, d_SA, d_stats, d_descs, d_misc;
 	uint64_t sa0_index = 0, num_sa = 0;
 	bool pos32 = true;                  /* BWT rows fit 32-bit positions */
 	bwb_params p{};
@@ -243,6 +243,13 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 		HIPCHK(hipEventRecord(ev_k[t].e, c->stream));
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
+#ifdef BWB_BKT64
+	HIPCHK(c->d_buckets64.alloc(nblk * 256));
+	hipLaunchKernelGGL(k_relayout64, dim3((unsigned)((nblk * 2 + 255) / 256)), dim3(256), 0, c->stream, c->d_buckets.as<uint4>(), nblk, c->d_buckets64.as<uint4>());
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->ix.buckets64 = c->d_buckets64.as<uint4>();
+#endif
 	*out = c.release();
 	return BWB_OK;
 }

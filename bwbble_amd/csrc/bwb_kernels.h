@@ -132,6 +132,40 @@ __global__ void k_relayout(const uint32_t *bwt, const uint64_t *O, uint64_t blk0
 	buckets[blk * 8 + sl] = o;
 }
 
+/* EXPERIMENT (-DBWB_BKT64, bwb_device.h): the 64-character buckets, derived from the 128-character ones.  One thread per new bucket. */
+__device__ __forceinline__ void sub_counts16(const uint4 p, uint32_t out[16]) {
+	const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
+	const uint32_t b[4] = { ~p.z & ~p.w, p.z & ~p.w, ~p.z & p.w, p.z & p.w };
+	for (int c = 0; c < 16; c++) out[c] = (uint32_t)__popc(a[c & 3] & b[c >> 2]);
+}
+__global__ void k_relayout64(const uint4 *b128, uint64_t nblk128, uint4 *b64) {
+	const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nblk128 * 2) return;
+	const uint4 *src = b128 + (t >> 1) * 8;
+	const int half = (int)(t & 1);
+	uint4 cnt[4] = { src[0], src[1], src[2], src[3] };
+	const uint4 s4 = src[4];
+	const uint4 pa = src[4 + 2 * half], pb = src[5 + 2 * half];
+	const uint32_t first = (s4.x & 1u) | ((s4.y & 1u) << 1) | ((s4.z & 1u) << 2) | ((s4.w & 1u) << 3);
+	uint32_t m0[16];
+	sub_counts16(pa, m0);
+	if (half) {
+		uint32_t h0[16], h1[16];
+		sub_counts16(src[4], h0); sub_counts16(src[5], h1);
+		for (int s = 0; s < 4; s++) {
+			cnt[s].x += h0[2 * s] + h1[2 * s]; cnt[s].y += h0[2 * s + 1] + h1[2 * s + 1];
+			cnt[s].z += h0[2 * s + 8] + h1[2 * s + 8]; cnt[s].w += h0[2 * s + 9] + h1[2 * s + 9];
+		}
+	}
+	uint32_t mid[4];
+	for (int s = 0; s < 4; s++) mid[s] = m0[2 * s] | (m0[2 * s + 1] << 8) | (m0[2 * s + 8] << 16) | (m0[2 * s + 9] << 24);
+	uint4 *dst = b64 + t * 8;
+	dst[0] = cnt[0]; dst[1] = cnt[1]; dst[2] = cnt[2]; dst[3] = cnt[3];
+	dst[4] = pa; dst[5] = pb;
+	dst[6] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+	dst[7] = make_uint4(first, 0u, 0u, 0u);
+}
+
 /* O_alphabet / exact Occ16 for a list of positions: one octet per query */
 __global__ __launch_bounds__(BWB_BLOCK) void k_rank16(DevIndex ix, const uint64_t *pos, uint64_t n, int inc, int exact, uint64_t *out) {
 	__shared__ uint64_t s_base[BWB_BASE_ROWS * 16];

@@ -120,10 +120,10 @@ template <typename P>
 __device__ __forceinline__ void pair_setup(P last_row, bool need, P pL, P pU, int lane, PairInfo<P> &pi) {
 	const bool negL = (pL == (P)~(P)0), endL = (pL == last_row), negU = (pU == (P)~(P)0), endU = (pU == last_row);
 	pi.regL = !(negL || endL); pi.regU = !(negU || endU);
-	pi.offL = (int)(pL & 127); pi.offU = (int)(pU & 127);
-	const P bL = pL >> 7, bU = pU >> 7;
-	pi.rowL = negL ? BWB_ROW_NEG : (endL ? BWB_ROW_END : (int)((uint64_t)bL >> BWB_SB_SHIFT));
-	pi.rowU = negU ? BWB_ROW_NEG : (endU ? BWB_ROW_END : (int)((uint64_t)bU >> BWB_SB_SHIFT));
+	pi.offL = (int)(pL & BKT_MASK); pi.offU = (int)(pU & BKT_MASK);
+	const P bL = pL >> BKT_SHIFT, bU = pU >> BKT_SHIFT;
+	pi.rowL = negL ? BWB_ROW_NEG : (endL ? BWB_ROW_END : (int)((uint64_t)bL >> BKT_SB_SHIFT));
+	pi.rowU = negU ? BWB_ROW_NEG : (endU ? BWB_ROW_END : (int)((uint64_t)bU >> BKT_SB_SHIFT));
 	pi.same = need && pi.regL && pi.regU && bL == bU;
 	const bool wantL = need && pi.regL, wantU = need && pi.regU && !pi.same;
 	pi.blkL = wantL ? (uint32_t)bL : NONE32; pi.blkU = wantU ? (uint32_t)bU : NONE32;
@@ -196,6 +196,54 @@ __device__ __forceinline__ void block_pops16(Lds<u32x4> row, int rot, int lo, in
 		p = pn;
 	}
 }
+#ifdef BWB_BKT64
+/* EXPERIMENT: rank from a 64-character bucket (bwb_device.h).  acc[j] = #j among the first n (0..32) characters of the sub-block whose
+ * planes are p, j = 1..15: ONE masked pass. */
+__device__ __forceinline__ void sub_pops16(const u32x4 p, int n, uint32_t acc[16]) {
+	const uint32_t m = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+	const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
+	const uint32_t m2 = m & ~p.z, m2p = m & p.z;
+	const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
+#pragma unroll
+	for (int c = 1; c < 16; c++) acc[c] = (uint32_t)__popc(a[c & 3] & b[c >> 2]);
+	acc[0] = 0;
+}
+/* what one side of a pair needs from its bucket row besides the counts: read BEFORE the row's upper half is overwritten */
+struct SideBits {
+	u32x4 planes;    /* of the sub-block the position is in */
+	u32x4 mid;       /* the counts inside the first sub-block as bytes, zero when the position is in the first sub-block */
+	uint32_t first;  /* first character of the enclosing 128-character block */
+	int n;           /* characters of the sub-block to count: (off & 31) + 1 */
+};
+__device__ __forceinline__ void side_read(Lds<u32x4> row, int rot, int off, SideBits &sb) {
+	const int w = off >> 5;
+	sb.planes = row[(4 + w + rot) & 7];
+	const u32x4 md = row[(6 + rot) & 7];
+	const u32x4 z = { 0u, 0u, 0u, 0u };
+	sb.mid = w ? md : z;
+	sb.first = ((Lds<uint32_t>)(row + ((7 + rot) & 7)))[0];
+	sb.n = (off & 31) + 1;
+}
+/* rel = counts (slices 0-3 of `cnt_row`) + mid + pass -> slices `dst0` .. `dst0 + 3` of the lane's own row; `quirk`: O_alphabet's view of 5, 9, 11, 13 */
+__device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const SideBits &sb, bool quirk, Lds<u32x4> own, int rot, int dst0) {
+	uint32_t acc[16];
+	sub_pops16(sb.planes, sb.n, acc);
+	const uint32_t md[4] = { sb.mid.x, sb.mid.y, sb.mid.z, sb.mid.w };
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		u32x4 q = cnt_row[(s + crot) & 7];
+		q.x += acc[2 * s] + (md[s] & 255u); q.y += acc[2 * s + 1] + ((md[s] >> 8) & 255u);
+		q.z += acc[2 * s + 8] + ((md[s] >> 16) & 255u); q.w += acc[2 * s + 9] + (md[s] >> 24);
+		if (quirk) { /* (codes 5, 9, 11, 13 are components {2,y}, {0,w}, {1,w}, {2,w}) */
+			if (s == 2) q.y = sb.first == 5u ? 0u : 1u;
+			if (s == 0) q.w = sb.first == 9u ? 0u : 1u;
+			if (s == 1) q.w = sb.first == 11u ? 0u : 1u;
+			if (s == 2) q.w = sb.first == 13u ? 0u : 1u;
+		}
+		own[(dst0 + s + rot) & 7] = q;
+	}
+}
+#endif
 /* index of code j in the count-slice order */
 __device__ __forceinline__ constexpr int cslot(int j) { return 4 * ((j & 7) >> 1) + (j & 1) + 2 * (j >> 3); }
 
@@ -238,6 +286,45 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
 	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
+#ifdef BWB_BKT64
+	/* Both sides are independent one-pass ranks.  A lane's own row is source (counts 0-3, planes and mid counts 4-7: side L, and side U of
+	 * a pair in one bucket) and destination (relL -> 0-3, relU -> 4-7): what side L needs from the upper half goes to registers first,
+	 * then side U is finished (it still finds the counts in the lower half), then side L. */
+	uint32_t ne = 0;
+	{
+		const bool haveL = pi.blkL != NONE32;
+		const Lds<u32x4> srcL = haveL ? own : zero_row;
+		const int rotL = haveL ? rot : 0;
+		SideBits bl;
+		side_read(srcL, rotL, pi.offL, bl);
+		for (int first = 0;; first += NU_MAX) {
+			if (first > 0) wave_gather<P>(buckets, pi, first, stage, lane); /* (rare: more than NU_MAX lanes of the wave with a second bucket) */
+			const bool fetched = pi.ku != NONE32;
+			const bool now = fetched ? ((int)pi.ku >= first && (int)pi.ku < first + NU_MAX) : first == 0;
+			if (now) {
+				const uint32_t k = pi.ku - (uint32_t)first;
+				const Lds<u32x4> src = fetched ? stage + 512 + k * 8 : (pi.same ? own : zero_row);
+				const int srot = fetched ? (int)((k >> 1) & 7) : (pi.same ? rot : 0);
+				SideBits bu;
+				side_read(src, srot, pi.offU, bu);
+				side_finish(src, srot, bu, kc.qU, own, rot, 4);
+			}
+			if (first == 0) {
+				__builtin_amdgcn_sched_barrier(0);
+				side_finish(srcL, rotL, bl, kc.qL, own, rot, 0); /* (a lane whose U row comes in a later round keeps relL in its row meanwhile) */
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			if (first + NU_MAX >= pi.nU) break;
+		}
+		/* non-empty children, when both positions have the same base row: relU > relL (component t of slice s is code {2s, 2s+1, 2s+8, 2s+9}[t]) */
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			const u32x4 l = own[(s + rot) & 7], q = own[(4 + s + rot) & 7];
+			ne |= (q.x > l.x ? 1u : 0u) << (2 * s) | (q.y > l.y ? 1u : 0u) << (2 * s + 1) | (q.z > l.z ? 1u : 0u) << (2 * s + 8) | (q.w > l.w ? 1u : 0u) << (2 * s + 9);
+		}
+	}
+	bool rows_differ = false;
+#else
 	{ /* side L: relL = counts + #j in [0, offL] -> slices 0-3 of the own row */
 		const bool have = pi.blkL != NONE32;
 		const Lds<u32x4> src = have ? own : zero_row;
@@ -296,6 +383,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 		}
 		if (first + NU_MAX >= pi.nU) break;
 	}
+#endif
 	rows_differ = need && pi.rowL != pi.rowU;
 	if (__any(rows_differ)) { /* a pair that straddles a superblock boundary or has a special position (the root's -1 / length-1): compare positions */
 		if (rows_differ) {
@@ -355,7 +443,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	Intv<P> *lbase = (Intv<P> *)sc.lists_d + (size_t)slot * 2 * sc.lcap;
 	const int cap = (int)sc.lcap;
+#ifdef BWB_BKT64
+	const uint4 *__restrict__ buckets = ix.buckets64;
+#else
 	const uint4 *__restrict__ buckets = ix.buckets;
+#endif
 	const P last_row = (P)(ix.length - 1);
 
 	bool active = false, done = false;
@@ -748,7 +840,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #endif
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
+#ifdef BWB_BKT64
+	const uint4 *__restrict__ buckets = ix.buckets64;
+#else
 	const uint4 *__restrict__ buckets = ix.buckets;
+#endif
 	const P last_row = (P)(ix.length - 1);
 	constexpr int ESZ = WIDE ? 2 : 1; /* uint4 per heap entry */
 
@@ -1429,6 +1525,25 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		const P pos = (P)(x % (ix.length - 1));
 		PairInfo<P> pi;
 		pair_setup<P>(last_row, q < n, pos, pos, lane, pi);
+#ifdef BWB_BKT64
+		wave_gather<P>(ix.buckets64, pi, 0, stage, lane);
+		uint32_t rel[16];
+		const bool own = pi.blkL != NONE32;
+		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
+		const int rot = own ? (lane >> 1) & 7 : 0;
+		{
+			SideBits bl;
+			side_read(row, rot, pi.offL, bl);
+			sub_pops16(bl.planes, bl.n, rel);
+			const uint32_t md[4] = { bl.mid.x, bl.mid.y, bl.mid.z, bl.mid.w };
+#pragma unroll
+			for (int s = 0; s < 4; s++) {
+				const u32x4 c4 = row[(s + rot) & 7];
+				rel[2 * s] += c4.x + (md[s] & 255u); rel[2 * s + 1] += c4.y + ((md[s] >> 8) & 255u);
+				rel[8 + 2 * s] += c4.z + ((md[s] >> 16) & 255u); rel[8 + 2 * s + 1] += c4.w + (md[s] >> 24);
+			}
+		}
+#else
 		wave_gather<P>(ix.buckets, pi, 0, stage, lane);
 		uint32_t rel[16], first = 0;
 #pragma unroll
@@ -1439,6 +1554,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		block_pops16(row, rot, 0, pi.offL, rel, first);
 #pragma unroll
 		for (int s = 0; s < 4; s++) { const u32x4 c4 = row[(s + rot) & 7]; rel[2 * s] += c4.x; rel[2 * s + 1] += c4.y; rel[8 + 2 * s] += c4.z; rel[8 + 2 * s + 1] += c4.w; }
+#endif
 		if (q < n) {
 			const P *brow = s_base + pi.rowL * 16;
 #pragma unroll
