@@ -36,6 +36,9 @@
  * the counts INSIDE the first sub-block as bytes (component s = {mid[2s], mid[2s+1], mid[2s+8], mid[2s+9]}), slice 7.x the code of
  * the first character of the enclosing 128-character block (O_alphabet's quirk, bwt.c:780).  A rank is then counts + (second
  * sub-block ? mid : 0) + ONE masked pass over one sub-block instead of four: 2 bytes of index per character instead of 1. */
+#if !defined(BWB_BKT128) && !defined(BWB_BKT64)
+#define BWB_BKT64 /* the product's layout since round 3; -DBWB_BKT128 builds the lane kernels on the 128-character buckets (A/B) */
+#endif
 #ifdef BWB_BKT64
 #define BKT_SHIFT 6
 #else
