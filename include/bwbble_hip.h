@@ -87,7 +87,8 @@ void bwb_default_params(bwb_params *p);                       /* align.c:22-38 *
 /* Creates a context on `device` and builds the device FM-index from the reference's in-memory
  * bwt_t arrays (mg-aligner/bwt.h:19-40, file layout bwt.c:66-82):
  *   hdr = {length, num_words, num_sa, num_occ, sa0_index}, C[17], bwt[num_words], O[num_occ*16].
- * The index is re-laid-out on the GPU into 128-byte rank buckets; the host arrays are
+ * The index is re-laid-out on the GPU into 128-byte rank buckets, in two granularities (128 characters per bucket for locate,
+ * 64 for the alignment kernels: 1 + 2 bytes of device memory per BWT character); the host arrays are
  * not referenced after return.  One context per device is the intended use: with the first batch a context sizes its heap
  * chunk pool from what the device has free (minus a reserve for the re-run classes and further slots), so a second context
  * on the same device - tests do that - should be given a budget with the environment variable BWB_POOL_GB. */
