@@ -20,8 +20,9 @@ EXPORTS = [
     "bwb_hip_device_count", "bwb_hip_last_error", "bwb_default_params", "bwb_hip_ctx_create", "bwb_hip_ctx_destroy",
     "bwb_hip_align_batch", "bwb_hip_batch_upload", "bwb_hip_batch_run", "bwb_hip_batch_result", "bwb_hip_get_stats",
     "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate",
-    "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush",
+    "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush", "bwb_hip_abi_version",
 ]
+ABI_VERSION = 2  # BWB_HIP_ABI_VERSION (include/bwbble_hip.h)
 MAX_SLOTS = 8  # BWB_MAX_SLOTS
 
 
@@ -46,8 +47,8 @@ class Stats(C.Structure):
                 ("launches_calc_d", C.c_uint32), ("launches_search", C.c_uint32)]
 
 
-ALN_DTYPE = np.dtype([("L", "<u8"), ("U", "<u8"), ("score", "u1"), ("num_mm", "u1"), ("num_gapo", "u1"),
-                      ("num_gape", "u1"), ("aln_length", "<u4"), ("gap_run", "<u2", (4,))])
+ALN_DTYPE = np.dtype([("L", "<u8"), ("U", "<u8"), ("score", "<u2"), ("num_mm", "u1"), ("num_gapo", "u1"),
+                      ("num_gape", "u1"), ("reserved", "u1"), ("aln_length", "<u2"), ("gap_run", "<u2", (4,))])
 assert ALN_DTYPE.itemsize == 32
 
 _FLAG = {"-M": "mm_score", "-O": "gapo_score", "-E": "gape_score", "-n": "max_diff", "-k": "max_diff_seed",
@@ -71,6 +72,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BwbError(f"{LIB_PATH} is missing: run `make -C bwbble_amd` (there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
+        if not hasattr(L, "bwb_hip_abi_version") or L.bwb_hip_abi_version() != ABI_VERSION:
+            raise BwbError(f"{LIB_PATH} implements another version of the C-ABI than this mirror (want {ABI_VERSION}): rebuild it")
         L.bwb_hip_last_error.restype = C.c_char_p
         L.bwb_hip_ctx_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.bwb_hip_ctx_destroy.argtypes = [C.c_void_p]

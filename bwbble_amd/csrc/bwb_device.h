@@ -5,15 +5,24 @@
  * per wave).  A rank-block visit is ONE coalesced 128-byte load: lane k of the octet loads bytes
  * [16k, 16k+16) of the bucket with a single global_load_dwordx4.
  *
- * Bucket (128 B, 128-byte aligned) for BWT positions [128b, 128b+127]  -- replaces the reference's
- * separate O row (128 B, bwt.c:288) + packed BWT words (64 B, io.c:590-609):
+ * Bucket (128 B, 128-byte aligned) for the 64 BWT positions [64b, 64b+63]  -- replaces the reference's
+ * separate O row (128 B per 128 positions, bwt.c:288) + packed BWT words (io.c:590-609):
  *   slice s=0..3 : uint32 {cnt[2s], cnt[2s+1], cnt[2s+8], cnt[2s+9]}
- *                  cnt[c] = #c in BWT[superblock_start .. 128b-1]  (EXCLUSIVE of this block, sentinel
+ *                  cnt[c] = #c in BWT[superblock_start .. 64b-1]  (EXCLUSIVE of this bucket, sentinel
  *                  row excluded as in compute_O bwt.c:284).
- *   slice 4+w    : uint32 {p0,p1,p2,p3} bit-planes of characters [32w, 32w+32): bit j of p_k is bit k
- *                  of the 4-bit code at block offset 32w+j.
+ *   slice 4+w    : uint32 {p0,p1,p2,p3} bit-planes of characters [32w, 32w+32), w = 0, 1: bit j of p_k is
+ *                  bit k of the 4-bit code at bucket offset 32w+j.
+ *   slice 6      : #c among the first 32 characters as bytes: component s = {mid[2s], mid[2s+1], mid[2s+8],
+ *                  mid[2s+9]} (the order of the count slices), so that a rank of a position in the second
+ *                  sub-block is counts + mid + ONE masked popcount pass (the lane kernels, bwb_lane.h).
+ *   slice 7      : .x = code of the first character of the enclosing 128-character block (what O_alphabet
+ *                  corrects by, bwt.c:780).
+ * 2 bytes of index per BWT character.  A 128-character bucket (1 byte per character) costs a rank four masked
+ * passes per side: measured 8-10 % slower in the alignment kernels (profiles/r3_bkt64_ab.txt); that layout and
+ * its lane path are kept as bwbble_amd/tools_exp/bkt128_lane_path.patch.
  * Absolute counts need > 32 bits on GRCh37-scale texts, so a superblock (2^24 blocks = 2^31 chars)
- * base table base[sb][c] = C[c] + #c before the superblock lives in LDS (<= 10 rows).
+ * base table base[sb][c] = C[c] + #c before the superblock lives in LDS (<= 10 rows).  Blocks below are the
+ * reference's 128-character O rows (DevIndex::nblk); a superblock is 2^(BWB_SB_SHIFT+1) buckets.
  *
  * Positions are a template parameter P: uint32_t when the BWT has < 2^32 - 1 rows (everything up
  * to ~2 G forward characters), uint64_t otherwise (GRCh37 + 1000G).  "-1" is ~P(0).
@@ -31,27 +40,14 @@
 #define BWB_ROW_END (BWB_NSB_MAX + 1)   /* base row for position length-1: C[j+1] (bwt.c:375-392) */
 #define BWB_BASE_ROWS (BWB_NSB_MAX + 2)
 
-/* EXPERIMENT (-DBWB_BKT64): the one-read-per-lane kernels rank from a second copy of the index with 64 characters per 128-byte
- * bucket: slices 0-3 the counts before the bucket (as above), slices 4-5 the planes of its two 32-character sub-blocks, slice 6
- * the counts INSIDE the first sub-block as bytes (component s = {mid[2s], mid[2s+1], mid[2s+8], mid[2s+9]}), slice 7.x the code of
- * the first character of the enclosing 128-character block (O_alphabet's quirk, bwt.c:780).  A rank is then counts + (second
- * sub-block ? mid : 0) + ONE masked pass over one sub-block instead of four: 2 bytes of index per character instead of 1. */
-#if !defined(BWB_BKT128) && !defined(BWB_BKT64)
-#define BWB_BKT64 /* the product's layout since round 3; -DBWB_BKT128 builds the lane kernels on the 128-character buckets (A/B) */
-#endif
-#ifdef BWB_BKT64
-#define BKT_SHIFT 6
-#else
-#define BKT_SHIFT 7
-#endif
+#define BKT_SHIFT 6                     /* characters per bucket = 64 */
 #define BKT_MASK ((1 << BKT_SHIFT) - 1)
 #define BKT_SB_SHIFT (BWB_SB_SHIFT + 7 - BKT_SHIFT) /* buckets per superblock: 2^31 characters either way */
 
 struct DevIndex {
-	const uint4 *buckets;               /* nblk * 8 slices */
-	const uint4 *buckets64;             /* -DBWB_BKT64: 2 * nblk * 8 slices, else null */
+	const uint4 *buckets;               /* 2 * nblk * 8 slices: one 128-byte bucket per 64 BWT characters */
 	uint64_t length;                    /* n + 1 (bwt_t.length) */
-	uint64_t nblk;
+	uint64_t nblk;                      /* 128-character blocks (the reference's O rows) */
 	uint64_t base[BWB_BASE_ROWS][16];
 };
 
@@ -96,8 +92,8 @@ __device__ __forceinline__ void rank_issue(const uint4 *__restrict__ buckets, P 
 	r.pos = pos;
 	const bool neg = (pos == (P)~(P)0), end = (pos == last_row);
 	r.regular = !(neg || end);
-	const P blk = pos >> 7;
-	r.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BWB_SB_SHIFT));
+	const P blk = pos >> BKT_SHIFT;
+	r.row = neg ? BWB_ROW_NEG : (end ? BWB_ROW_END : (int)((uint64_t)blk >> BKT_SB_SHIFT));
 	r.q = make_uint4(0, 0, 0, 0);
 	if (r.regular) r.q = buckets[(size_t)blk * 8 + ol];
 }
@@ -111,10 +107,10 @@ __device__ __forceinline__ void rank_issue(const uint4 *__restrict__ buckets, P 
 template <typename P, bool QUIRK>
 __device__ __forceinline__ void rank_finish(const RankReq<P> &r, const P *s_base, int ol, int lane, P &v0, P &v1, uint32_t *first_out = nullptr) {
 	const uint4 q = r.q;
-	/* position mask of this lane's 32-character sub-block (lanes 0..3 hold counts: empty mask) */
-	const int off = (int)(r.pos & 127);
+	/* position mask of this lane's 32-character sub-block (lanes 4 and 5 hold planes; 0..3 counts, 6 the mid counts, 7 the first character: empty mask) */
+	const int off = (int)(r.pos & BKT_MASK);
 	const int nvalid = off + 1 - 32 * (ol - 4);
-	const uint32_t m = (ol < 4 || nvalid <= 0 || !r.regular) ? 0u : (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
+	const uint32_t m = (ol < 4 || ol > 5 || nvalid <= 0 || !r.regular) ? 0u : (nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u));
 	const uint32_t p0 = q.x, p1 = q.y, p2 = q.z, p3 = q.w;
 	const uint32_t n0 = ~p0, n1 = ~p1;
 	const uint32_t a0 = n0 & n1, a1 = p0 & n1, a2 = n0 & p1, a3 = p0 & p1;                 /* code & 3  */
@@ -137,11 +133,11 @@ __device__ __forceinline__ void rank_finish(const RankReq<P> &r, const P *s_base
 	const P *brow = s_base + r.row * 16 + 2 * ol;
 	v0 = brow[0] + c0 + pop0;
 	v1 = brow[1] + c1 + pop1;
-	if (first_out) /* first character of the block: bit 0 of the four planes held by lane 4 */
-		*first_out = oct_bcast((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);
+	if (first_out) /* first character of the enclosing 128-character block: slice 7 */
+		*first_out = oct_bcast(q.x, (lane & ~7) + 7);
 	if (QUIRK) {
-		/* first character of the block (bwt.c:780): bit 0 of the four planes held by lane 4 */
-		const uint32_t first = oct_bcast((q.x & 1u) | ((q.y & 1u) << 1) | ((q.z & 1u) << 2) | ((q.w & 1u) << 3), (lane & ~7) + 4);
+		/* first character of the enclosing 128-character block (bwt.c:780): slice 7 */
+		const uint32_t first = oct_bcast(q.x, (lane & ~7) + 7);
 		const int j1 = 2 * ol + 1; /* only odd codes 5, 9, 11, 13 (lanes 2, 4, 5, 6) */
 		if (r.regular && (j1 == 5 || j1 == 9 || j1 == 11 || j1 == 13))
 			v1 = s_base[BWB_ROW_NEG * 16 + j1] - (first == (uint32_t)j1 ? (P)1 : (P)0);

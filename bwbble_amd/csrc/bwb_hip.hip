@@ -116,7 +116,7 @@ struct bwb_hip_ctx {
 	int device = 0, num_cu = 0;
 	hipStream_t stream = nullptr, cstream = nullptr, rstream = nullptr; /* kernels; uploads; results */
 	DevIndex ix{};
-	DevMem d_buckets, d_buckets64, d_SA, d_stats, d_descs, d_misc;
+	DevMem d_buckets, d_SA, d_stats, d_descs, d_misc;
 	uint64_t sa0_index = 0, num_sa = 0;
 	bool pos32 = true;                  /* BWT rows fit 32-bit positions */
 	bwb_params p{};
@@ -151,6 +151,7 @@ struct bwb_hip_ctx {
 };
 
 extern "C" const char *bwb_hip_last_error(void) { return g_err.c_str(); }
+extern "C" int bwb_hip_abi_version(void) { return BWB_HIP_ABI_VERSION; }
 
 extern "C" int bwb_hip_device_count(void) {
 	int n = 0;
@@ -189,7 +190,7 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
 	HIPCHK(hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking));
-	HIPCHK(c->d_buckets.alloc(nblk * 128));
+	HIPCHK(c->d_buckets.alloc(nblk * 256)); /* 64-character buckets: 2 bytes per BWT character */
 	HIPCHK(c->d_stats.alloc(sizeof(unsigned long long) * STAT_WORDS));
 	HIPCHK(c->d_descs.alloc(sizeof(SlotDesc) * BWB_MAX_SLOTS));
 	HIPCHK(c->d_misc.alloc(256));
@@ -216,14 +217,16 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	c->sa0_index = hdr[4];
 	c->pos32 = length < 0xFFFFFFFFull && !getenv("BWB_FORCE_POS64");
 
-	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk; the two staging sets alternate so that the copy of
-	 * chunk k+1 overlaps the kernel of chunk k */
+	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk: reference arrays -> 128-character buckets in a staging
+	 * buffer (k_relayout) -> the index's 64-character buckets (k_relayout64); the two staging sets alternate so that the copy
+	 * of chunk k+1 overlaps the kernels of chunk k */
 	const uint64_t CH = 1ull << 20;
-	DevMem d_bwt[2], d_O[2], d_sbc;
+	DevMem d_bwt[2], d_O[2], d_b128[2], d_sbc;
 	Event ev_k[2];
 	for (int t = 0; t < 2; t++) {
 		HIPCHK(d_bwt[t].alloc(std::min(CH, nblk) * 64));
 		HIPCHK(d_O[t].alloc(std::min(CH, nblk) * 128));
+		HIPCHK(d_b128[t].alloc(std::min(CH, nblk) * 128));
 		HIPCHK(ev_k[t].create());
 	}
 	HIPCHK(d_sbc.alloc(sbcount.size() * 8));
@@ -238,18 +241,13 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 		HIPCHK(hipMemcpyAsync(d_O[t].p, O + b0 * 16, nb * 128, hipMemcpyHostToDevice, c->stream));
 		const uint64_t nthreads = nb * 8;
 		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt[t].as<uint32_t>(), d_O[t].as<uint64_t>(), b0, nb, nw,
-		                   hdr[4], d_sbc.as<uint64_t>(), c->d_buckets.as<uint4>());
+		                   hdr[4], d_sbc.as<uint64_t>(), d_b128[t].as<uint4>());
+		HIPCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_relayout64, dim3((unsigned)((nb * 2 + 255) / 256)), dim3(256), 0, c->stream, d_b128[t].as<uint4>(), nb, c->d_buckets.as<uint4>() + b0 * 16);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev_k[t].e, c->stream));
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
-#ifdef BWB_BKT64
-	HIPCHK(c->d_buckets64.alloc(nblk * 256));
-	hipLaunchKernelGGL(k_relayout64, dim3((unsigned)((nblk * 2 + 255) / 256)), dim3(256), 0, c->stream, c->d_buckets.as<uint4>(), nblk, c->d_buckets64.as<uint4>());
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(c->stream));
-	c->ix.buckets64 = c->d_buckets64.as<uint4>();
-#endif
 	*out = c.release();
 	return BWB_OK;
 }
@@ -261,11 +259,6 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 	delete c;
 }
 
-#ifdef BWB_LOCAL_RECS
-#define LOCAL_RECS_BUILD 1
-#else
-#define LOCAL_RECS_BUILD 0
-#endif
 static size_t lane_lds(const bwb_hip_ctx *c) {
 	(void)c;
 	return (size_t)LDS_WAVES_OFF + (size_t)(LANE_BLOCK / 64) * WAVE_LDS_BYTES; /* base table + zero row + per wave: gather staging / children */
@@ -354,10 +347,10 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
 	const uint32_t brow = std::max<uint32_t>(BSTATE_ROW_MIN, ((uint32_t)c->kp.num_buckets + 63u) & ~63u);
 	const size_t b_bstate = al((size_t)brow * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
-	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16), b_recs = al((size_t)nslots * LANE_RECS * 8) * LOCAL_RECS_BUILD;
+	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16);
 	/* class 0 runs kl_calc_d of the next batch while parked reads keep their lists: it gets a second set; the re-run classes
 	 * are drained before anything else uses them */
-	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_recs + b_save + b_bsave;
+	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_save + b_bsave;
 	if (!(s.mem.p && s.mem.bytes >= bytes)) {
 		if (k == 0 && c->parked) return fail(BWB_E_STATE, "the class-0 scratch cannot grow while reads are parked (flush first)");
 		s.mem.release();
@@ -373,10 +366,9 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	s.sc.lists_d = s.sc.lists;
 	if (k == 0) { s.sc.lists_d = (void *)base; base += b_lists; }
 	s.sc.alns = (uint4 *)base; base += b_alns;
-	s.sc.winfo = (uint2 *)base; base += b_recs;
 	s.sc.save = (uint4 *)base; base += b_save;
 	s.sc.blocksave = (uint32_t *)base;
-	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.wstride = LANE_RECS; s.sc.brow = brow;
+	s.sc.nslots = nslots; s.sc.lcap = lcap; s.sc.acap = acap; s.sc.brow = brow;
 	s.sc.keep = c->keep;
 	s.blocks = blocks;
 	s.ready = true;

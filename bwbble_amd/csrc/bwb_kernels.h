@@ -1,7 +1,7 @@
 /*
  * bwb_kernels.h - shared kernel-side types and the utility kernels (gfx950).  Included by bwb_hip.hip.
  *
- *   k_relayout   reference .bwt arrays -> 128-byte rank buckets (bwb_device.h)
+ *   k_relayout, k_relayout64   reference .bwt arrays -> 128-byte rank buckets of 64 characters (bwb_device.h)
  *   k_rank16     O_alphabet / O for a list of positions (parity tests), octet-cooperative rank
  *   k_rank_bench random-position rank micro-benchmark (octet-cooperative rank)
  *   k_locate     SA[row] by the invPsi walk (aln2sam)
@@ -129,10 +129,10 @@ __global__ void k_relayout(const uint32_t *bwt, const uint64_t *O, uint64_t blk0
 		}
 		o = make_uint4(p[0], p[1], p[2], p[3]);
 	}
-	buckets[blk * 8 + sl] = o;
+	buckets[lb * 8 + sl] = o; /* (chunk-local: the 128-character form only lives in a staging buffer, k_relayout64 below makes the index) */
 }
 
-/* EXPERIMENT (-DBWB_BKT64, bwb_device.h): the 64-character buckets, derived from the 128-character ones.  One thread per new bucket. */
+/* The index proper (bwb_device.h): 64-character buckets, derived from a chunk of 128-character ones.  One thread per new bucket. */
 __device__ __forceinline__ void sub_counts16(const uint4 p, uint32_t out[16]) {
 	const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
 	const uint32_t b[4] = { ~p.z & ~p.w, p.z & ~p.w, ~p.z & p.w, p.z & p.w };
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_
 			if (i == sa0_index) { i = 0; j++; continue; } /* invPsi bwt.c:312-314 */
 			RankReq<uint64_t> ra;
 			rank_issue<uint64_t>(ix.buckets, ix.length - 1, i, ol, ra);
-			/* B(i), bwt.c:337-345: bit (i&31) of the planes held by lane 4 + ((i&127)>>5) */
-			const uint4 cq = ra.regular ? ra.q : ix.buckets[(i >> 7) * 8 + ol]; /* i == length-1 is not ranked via its bucket */
-			const int off = (int)(i & 127), srcl = (lane & ~7) + 4 + (off >> 5), bit = off & 31;
+			/* B(i), bwt.c:337-345: bit (i&31) of the planes held by lane 4 + ((i&63)>>5) */
+			const uint4 cq = ra.regular ? ra.q : ix.buckets[(i >> BKT_SHIFT) * 8 + ol]; /* i == length-1 is not ranked via its bucket */
+			const int off = (int)(i & BKT_MASK), srcl = (lane & ~7) + 4 + (off >> 5), bit = off & 31;
 			const uint32_t code_here = ((cq.x >> bit) & 1u) | (((cq.y >> bit) & 1u) << 1) | (((cq.z >> bit) & 1u) << 2) | (((cq.w >> bit) & 1u) << 3);
 			const uint32_t code = oct_bcast(code_here, srcl);
 			uint64_t v0, v1;

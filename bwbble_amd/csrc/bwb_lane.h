@@ -47,7 +47,6 @@ template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 #define SAVE_U4 16               /* uint4 per lane in the save area */
-#define LANE_RECS 258            /* 8-byte per-position records per lane: positions 0 .. 256 + 1 of a read of at most 255 bases */
 
 struct LaneScratch {
 	uint4 *pool;                /* chunk pool in POOL_REGIONS regions (block b uses region b % n_regions: its XCD's when all 8 are in use):
@@ -64,9 +63,7 @@ struct LaneScratch {
 	uint4 *save;                /* [nslots][SAVE_U4]: a lane's read, parked at the end of a slice (word 0 bit 0 = occupied) */
 	uint32_t *blocksave;        /* [blocks][4]: a block's recycle stack {~head lo, ~head hi, chunks, -} across slices */
 	uint4 *alns;                /* [nslots][acap*2] */
-	uint2 *winfo;               /* [nslots][wstride]: the per-position records of the read a lane is working on (copied from the slot's
-	                               buffer when the read starts: kl_search) */
-	uint32_t nslots, lcap, acap, wstride;
+	uint32_t nslots, lcap, acap;
 	uint32_t brow;              /* bucket states per lane */
 };
 
@@ -172,33 +169,8 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	__builtin_amdgcn_wave_barrier();
 }
 
-/* acc[] += #j among the characters [lo, hi] of the block whose planes are in `row` (slices 4-7, slice k at row[(k + rot) & 7]), j = 1..15:
- * acc[j] for j < 8 is component (j & 1) of count slice j >> 1, acc[8 + c] (code 8 + c) component 2 + (c & 1) of slice c >> 1.
- * `first` = code of the block's first character (bwt.c:780).  One sub-block at a time, the next one's planes on their way: 8 plane
- * words live, not the 32 of the bucket. */
-__device__ __forceinline__ void block_pops16(Lds<u32x4> row, int rot, int lo, int hi, uint32_t acc[16], uint32_t &first) {
-	u32x4 p = row[(4 + rot) & 7];
-	first = (p.x & 1u) | ((p.y & 1u) << 1) | ((p.z & 1u) << 2) | ((p.w & 1u) << 3);
-#pragma unroll
-	for (int w = 0; w < 4; w++) {
-		u32x4 pn = p;
-		if (w < 3) pn = row[(4 + w + 1 + rot) & 7];
-		const int nh = hi + 1 - 32 * w, nl = lo - 32 * w;
-		const uint32_t mh = nh <= 0 ? 0u : (nh >= 32 ? 0xFFFFFFFFu : ((1u << nh) - 1u));
-		const uint32_t ml = nl <= 0 ? 0u : (nl >= 32 ? 0xFFFFFFFFu : ((1u << nl) - 1u));
-		const uint32_t m = mh & ~ml;
-		const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
-		const uint32_t m2 = m & ~p.z, m2p = m & p.z;
-		const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
-#pragma unroll
-		for (int c = 1; c < 16; c++) acc[(c & 7) + 8 * (c >> 3)] += __popc(a[c & 3] & b[c >> 2]);
-		__builtin_amdgcn_sched_barrier(0);
-		p = pn;
-	}
-}
-#ifdef BWB_BKT64
-/* EXPERIMENT: rank from a 64-character bucket (bwb_device.h).  acc[j] = #j among the first n (0..32) characters of the sub-block whose
- * planes are p, j = 1..15: ONE masked pass. */
+/* Rank from a 64-character bucket (bwb_device.h): acc[j] = #j among the first n (0..32) characters of the sub-block whose planes are p,
+ * j = 1..15: ONE masked pass. */
 __device__ __forceinline__ void sub_pops16(const u32x4 p, int n, uint32_t acc[16]) {
 	const uint32_t m = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
 	const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
@@ -243,7 +215,6 @@ __device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const 
 		own[(dst0 + s + rot) & 7] = q;
 	}
 }
-#endif
 /* index of code j in the count-slice order */
 __device__ __forceinline__ constexpr int cslot(int j) { return 4 * ((j & 7) >> 1) + (j & 1) + 2 * (j >> 3); }
 
@@ -286,7 +257,6 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
 	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
-#ifdef BWB_BKT64
 	/* Both sides are independent one-pass ranks.  A lane's own row is source (counts 0-3, planes and mid counts 4-7: side L, and side U of
 	 * a pair in one bucket) and destination (relL -> 0-3, relU -> 4-7): what side L needs from the upper half goes to registers first,
 	 * then side U is finished (it still finds the counts in the lower half), then side L. */
@@ -323,68 +293,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 			ne |= (q.x > l.x ? 1u : 0u) << (2 * s) | (q.y > l.y ? 1u : 0u) << (2 * s + 1) | (q.z > l.z ? 1u : 0u) << (2 * s + 8) | (q.w > l.w ? 1u : 0u) << (2 * s + 9);
 		}
 	}
-	bool rows_differ = false;
-#else
-	{ /* side L: relL = counts + #j in [0, offL] -> slices 0-3 of the own row */
-		const bool have = pi.blkL != NONE32;
-		const Lds<u32x4> src = have ? own : zero_row;
-		const int srot = have ? rot : 0;
-		uint32_t fL = 0, a01[16];
-#pragma unroll
-		for (int c = 0; c < 16; c++) a01[c] = 0;
-		block_pops16(src, srot, 0, pi.offL, a01, fL);
-		uint32_t *a0 = a01, *a1 = a01 + 8;
-#pragma unroll
-		for (int s = 0; s < 4; s++) {
-			u32x4 q = src[(s + srot) & 7];
-			q.x += a0[2 * s]; q.y += a0[2 * s + 1]; q.z += a1[2 * s]; q.w += a1[2 * s + 1];
-			if (kc.qL) { /* (codes 5, 9, 11, 13 are components {2,y}, {0,w}, {1,w}, {2,w}) */
-				if (s == 2) q.y = fL == 5u ? 0u : 1u;
-				if (s == 0) q.w = fL == 9u ? 0u : 1u;
-				if (s == 1) q.w = fL == 11u ? 0u : 1u;
-				if (s == 2) q.w = fL == 13u ? 0u : 1u;
-			}
-			own[(s + rot) & 7] = q;
-		}
-		__builtin_amdgcn_sched_barrier(0);
-	}
-	/* side U: from the lane's own row (same bucket: relL + the characters in between), from its compacted U row, or nothing to count */
-	uint32_t ne = 0;
-	bool rows_differ = false;
-	for (int first = 0;; first += NU_MAX) {
-		if (first > 0) wave_gather<P>(buckets, pi, first, stage, lane); /* (rare: more than NU_MAX lanes of the wave with a second bucket) */
-		const bool fetched = pi.ku != NONE32;
-		const bool now = fetched ? ((int)pi.ku >= first && (int)pi.ku < first + NU_MAX) : first == 0;
-		if (now) {
-			const uint32_t k = pi.ku - (uint32_t)first;
-			const Lds<u32x4> src = fetched ? stage + 512 + k * 8 : (pi.same ? own : zero_row);
-			const int srot = fetched ? (int)((k >> 1) & 7) : (pi.same ? rot : 0);
-			const int lo = pi.same ? pi.offL + 1 : 0;
-			uint32_t fU = 0, a01[16];
-#pragma unroll
-			for (int c = 0; c < 16; c++) a01[c] = 0;
-			block_pops16(src, srot, lo, pi.offU, a01, fU); /* (the own row's planes are read before relU overwrites them) */
-			uint32_t *a0 = a01, *a1 = a01 + 8;
-#pragma unroll
-			for (int s = 0; s < 4; s++) {
-				u32x4 q = src[(s + srot) & 7];          /* same bucket: relL (written above); else the U bucket's counts */
-				const u32x4 l = own[(s + rot) & 7];      /* relL */
-				q.x += a0[2 * s]; q.y += a0[2 * s + 1]; q.z += a1[2 * s]; q.w += a1[2 * s + 1];
-				if (kc.qU) {
-					if (s == 2) q.y = fU == 5u ? 0u : 1u;
-					if (s == 0) q.w = fU == 9u ? 0u : 1u;
-					if (s == 1) q.w = fU == 11u ? 0u : 1u;
-					if (s == 2) q.w = fU == 13u ? 0u : 1u;
-				}
-				/* non-empty children, when both positions have the same base row: relU > relL (component t of slice s is code {2s, 2s+1, 2s+8, 2s+9}[t]) */
-				ne |= (q.x > l.x ? 1u : 0u) << (2 * s) | (q.y > l.y ? 1u : 0u) << (2 * s + 1) | (q.z > l.z ? 1u : 0u) << (2 * s + 8) | (q.w > l.w ? 1u : 0u) << (2 * s + 9);
-				own[(4 + s + rot) & 7] = q;
-			}
-		}
-		if (first + NU_MAX >= pi.nU) break;
-	}
-#endif
-	rows_differ = need && pi.rowL != pi.rowU;
+	const bool rows_differ = need && pi.rowL != pi.rowU;
 	if (__any(rows_differ)) { /* a pair that straddles a superblock boundary or has a special position (the root's -1 / length-1): compare positions */
 		if (rows_differ) {
 			ne = 0;
@@ -443,11 +352,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	Intv<P> *lbase = (Intv<P> *)sc.lists_d + (size_t)slot * 2 * sc.lcap;
 	const int cap = (int)sc.lcap;
-#ifdef BWB_BKT64
-	const uint4 *__restrict__ buckets = ix.buckets64;
-#else
 	const uint4 *__restrict__ buckets = ix.buckets;
-#endif
 	const P last_row = (P)(ix.length - 1);
 
 	bool active = false, done = false;
@@ -831,20 +736,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
 #define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
 #define mysave (sc.save + (size_t)slotv * SAVE_U4)
-	/* Experiment kept as a build option (make exp X=localrecs XFLAGS=-DBWB_LOCAL_RECS): the read's per-position records {D pair, D_seed pair,
-	 * base} copied from the slot's buffer into the lane's scratch when the read starts, so that the one record load per iteration goes to a
-	 * page the whole block shares instead of 64 different 2 MB pages of a 16 GB region per wave instruction.  Measured at GRCh37 scale:
-	 * 267.4 k against 270.3 k reads/s without it (tools/r3_s10.sh) - the record load is not what the gather waits for.  Off. */
-#ifdef BWB_LOCAL_RECS
-#define recs ((const uint2 *)(sc.winfo + (size_t)slotv * sc.wstride))
-#endif
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
-#ifdef BWB_BKT64
-	const uint4 *__restrict__ buckets = ix.buckets64;
-#else
 	const uint4 *__restrict__ buckets = ix.buckets;
-#endif
 	const P last_row = (P)(ix.length - 1);
 	constexpr int ESZ = WIDE ? 2 : 1; /* uint4 per heap entry */
 
@@ -872,9 +766,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	h.top = e;
 #define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
-#ifndef BWB_LOCAL_RECS
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
-#endif
 	uint32_t rec_x = 0, rec_y = 0; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
@@ -896,7 +788,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		exact_mode = ((fl >> 1) & 1u) != 0; cursel = ((fl >> 2) & 1u) != 0; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
 		myslot = (fl >> 8) & 0xFFu;
 		rid = a0.y;
-		len = (int)(a0.z & 255u); best_score = (int)((a0.z >> 8) & 255u); max_diff = (int)((a0.z >> 16) & 255u);
+		len = (int)(a0.z & 255u); max_diff = (int)((a0.z >> 16) & 255u); best_score = (int)a2.x; /* (best_score: up to 1 024 buckets, its own word) */
 		num_best = (int)a0.w;
 		n_alns = (int)a1.x; r = (int)a1.y; s = (int)a1.z; curT = (int)a1.w;
 		nx.T = (int)a2.y; cL = p64(a2.z, a2.w);
@@ -913,9 +805,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z;
 		nxw = mysave[14].x;
 		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
-#ifndef BWB_LOCAL_RECS
 		recs = (const uint2 *)(descs[myslot].b.dbuf + (size_t)rid * descs[myslot].b.dstride);
-#endif
 		rec_ok = false;
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -958,15 +848,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const bool unrep = len == BAD_LEN;
 				if (unrep) len = 0;
 				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
-#ifndef BWB_LOCAL_RECS
 				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
-#else
-				{
-					const uint2 *src = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
-					uint2 *dst = sc.winfo + (size_t)slotv * sc.wstride;
-					for (int i = 0; i <= len + 1; i++) dst[i] = src[i];
-				}
-#endif
 				rec_ok = false;
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
@@ -1016,9 +898,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				auto hi = [](P v) { return (uint32_t)((uint64_t)v >> 32); };
 				const uint32_t fl = 1u | ((exact_mode ? 1u : 0u) << 1) | ((cursel ? 1u : 0u) << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
 				                    ((h.top_valid ? 1u : 0u) << 5) | (myslot << 8);
-				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)best_score << 8) | ((uint32_t)max_diff << 16), (uint32_t)num_best);
+				mysave[0] = make_uint4(fl, rid, (uint32_t)len | ((uint32_t)max_diff << 16), (uint32_t)num_best);
 				mysave[1] = make_uint4((uint32_t)n_alns, (uint32_t)r, (uint32_t)s, (uint32_t)curT);
-				mysave[2] = make_uint4(0u, (uint32_t)nx.T, lo(cL), hi(cL));
+				mysave[2] = make_uint4((uint32_t)best_score, (uint32_t)nx.T, lo(cL), hi(cL));
 				mysave[3] = make_uint4(lo(cU), hi(cU), lo(nx.tL), hi(nx.tL));
 				mysave[4] = make_uint4(lo(nx.tU), hi(nx.tU), lo(nxi.L), hi(nxi.L));
 				mysave[5] = make_uint4(lo(nxi.U), hi(nxi.U), lo(e.L), hi(e.L));
@@ -1059,7 +941,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			}
 			if (n_alns >= (int)sc.acap) { ovf = true; return; }
 			myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
-			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 255) | (e.f & 0xFFFFFF00u), (uint32_t)(alen & 255), e.runsLo, e.runsHi);
+			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), e.runsLo, e.runsHi); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
 			n_alns++;
 		};
 
@@ -1079,7 +961,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the
 				 * group's last child, which happens in the next iteration, once the children are in place */
 				if (!is_group) r_pop++;
-				if (e_score > best_score + kp.mm_score) { finish = true; if (is_group) r_pop++; } /* :309 (the reference pops that child, then stops) */
+				/* :309 (the reference pops that child, then stops).  aln_entry_t.score is an 8-bit field (align.h:104): what the reference compares is
+				 * the score modulo 256 - the same number unless the parameters allow scores above 255 */
+				if ((e_score & 255) > best_score + kp.mm_score) { finish = true; if (is_group) r_pop++; }
 				else {
 					from_pop = true;
 					widx = (int)(e.f & 255u);
@@ -1148,9 +1032,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const int e_state = (int)(e.sa & 3u);
 		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
 		uint32_t stX = NONE32, stG = NONE32;
-#ifdef BWB_EAGER_BSTATE /* rounds 1-2: both side buckets' states fetched for every popped entry, whether or not the expansion pushes to them */
-		if (from_pop) { stX = h.bstate[scX < nb ? scX : nb - 1]; stG = h.bstate[scG < nb ? scG : nb - 1]; }
-#endif
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
 		if (!kp.multiref) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
@@ -1254,12 +1135,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const int k2 = tG == 2 ? nG : 0;
 					STAMP(9);
 					uint32_t st0 = h.reserve(h.cst, k0, ovf);
-#ifndef BWB_EAGER_BSTATE
 					/* the side buckets' states, only when the expansion pushes to them (mismatches: 8 % of the expansions, gaps: 31 %): 1.6 fewer
 					 * memory requests per iteration than fetching both for every popped entry, +1.8 % at GRCh37 scale (profiles/r3_ab_steps.txt) */
 					if (k1 > 0) stX = h.bstate[scX];
 					if (k2 > 0) stG = h.bstate[scG];
-#endif
 					uint32_t st1 = h.reserve(stX, k1, ovf);
 					uint32_t st2 = h.reserve(stG, k2, ovf);
 					STAMP(10);
@@ -1499,9 +1378,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #undef myalns
 #undef mysave
 #undef e_score
-#ifdef BWB_LOCAL_RECS
-#undef recs
-#endif
 
 /* Rank micro-benchmark, lane layout: one query per lane - the wave gathers the 64 buckets cooperatively (wave_gather, L rows
  * only) and every lane ranks all 15 codes of its own bucket from LDS (block_pops): the access pattern and the ALU work of a rank
@@ -1525,8 +1401,7 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		const P pos = (P)(x % (ix.length - 1));
 		PairInfo<P> pi;
 		pair_setup<P>(last_row, q < n, pos, pos, lane, pi);
-#ifdef BWB_BKT64
-		wave_gather<P>(ix.buckets64, pi, 0, stage, lane);
+		wave_gather<P>(ix.buckets, pi, 0, stage, lane);
 		uint32_t rel[16];
 		const bool own = pi.blkL != NONE32;
 		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
@@ -1543,18 +1418,6 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 				rel[8 + 2 * s] += c4.z + ((md[s] >> 16) & 255u); rel[8 + 2 * s + 1] += c4.w + (md[s] >> 24);
 			}
 		}
-#else
-		wave_gather<P>(ix.buckets, pi, 0, stage, lane);
-		uint32_t rel[16], first = 0;
-#pragma unroll
-		for (int c = 0; c < 16; c++) rel[c] = 0;
-		const bool own = pi.blkL != NONE32;
-		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
-		const int rot = own ? (lane >> 1) & 7 : 0;
-		block_pops16(row, rot, 0, pi.offL, rel, first);
-#pragma unroll
-		for (int s = 0; s < 4; s++) { const u32x4 c4 = row[(s + rot) & 7]; rel[2 * s] += c4.x; rel[2 * s + 1] += c4.y; rel[8 + 2 * s] += c4.z; rel[8 + 2 * s + 1] += c4.w; }
-#endif
 		if (q < n) {
 			const P *brow = s_base + pi.rowL * 16;
 #pragma unroll

@@ -108,6 +108,7 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_interva
 	printf("BWBBLE Inexact Alignment (MI355X)...\n");
 	FILE *alnFile = fopen(alnFname, "a+b");                                   /* inexact_match.c:94 */
 	if (!alnFile) { perror(alnFname); bwb_die("align_reads_inexact: Cannot open ALN file: %s!", alnFname); }
+	if (bwb_hip_abi_version() != BWB_HIP_ABI_VERSION) bwb_die("align_reads_inexact_gpu: libbwbble_hip.so implements C-ABI version %d, this binary was compiled against %d", bwb_hip_abi_version(), BWB_HIP_ABI_VERSION);
 	const int ndev = bwb_hip_device_count();
 	if (ndev < 1) bwb_die("align_reads_inexact_gpu: no HIP device found (this build has no CPU alignment path)");
 	/* BWB_DEVICE_MAP=d0,d1,...: worker g drives HIP device d_g (default g).  Several workers on one device are allowed - that

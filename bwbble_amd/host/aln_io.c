@@ -64,8 +64,8 @@ alns_batch_t *alnsf2alns_bin(const char *alnFname) {
 			int32_t score, v[4], pairs;
 			if (fread(&score, 4, 1, f) < 1 || fread(&a->L, 8, 1, f) < 1 || fread(&a->U, 8, 1, f) < 1 || fread(v, 4, 4, f) < 4 || fread(&pairs, 4, 1, f) < 1)
 				bwb_die("alnsf2alns: Could not read ALN file: %s!", alnFname);
-			a->score = (uint8_t)score; a->num_mm = (uint8_t)v[0]; a->num_gapo = (uint8_t)v[1]; a->num_gape = (uint8_t)v[2];
-			a->aln_length = (uint32_t)v[3];
+			a->score = (uint16_t)score; a->num_mm = (uint8_t)v[0]; a->num_gapo = (uint8_t)v[1]; a->num_gape = (uint8_t)v[2];
+			a->aln_length = (uint16_t)v[3]; a->reserved = 0;
 			for (int k = 0; k < 4; k++) a->gap_run[k] = 0xFFFF;
 			/* The reference loader fills aln_path in PAIR order (align.c:466-476), i.e. the loaded path is the
 			 * align-time path reversed (pairs were written from index aln_length-1 down to 0, align.c:363-373);

@@ -43,8 +43,10 @@ typedef struct {
  * run = start_index_in_path | (run_length << 8) | (is_deletion << 15); unused runs are 0xFFFF. */
 typedef struct {
 	uint64_t L, U;           /* SA interval */
-	uint8_t score, num_mm, num_gapo, num_gape;
-	uint32_t aln_length;     /* 8-bit wrapped like aln_entry_t.aln_length (align.h:104) */
+	uint16_t score;          /* aln_t.score: the full int aln_score(num_mm, num_gapo, num_gape) (inexact_match.c:332,348); up to 1 024 heap
+	                            buckets are accepted, so it does not fit the 8 bits it had in ABI version 1 */
+	uint8_t num_mm, num_gapo, num_gape, reserved;
+	uint16_t aln_length;     /* 8-bit wrapped like aln_entry_t.aln_length (align.h:104) */
 	uint16_t gap_run[4];
 } bwb_aln;
 
@@ -80,6 +82,11 @@ typedef struct {
 
 typedef struct bwb_hip_ctx bwb_hip_ctx;
 
+/* Version of this interface: 2 since bwb_aln.score is 16 bits wide (round 4).  A binding compiled against another version must not
+ * be used with the library: compare BWB_HIP_ABI_VERSION with bwb_hip_abi_version() at start-up. */
+#define BWB_HIP_ABI_VERSION 2
+int bwb_hip_abi_version(void);
+
 int bwb_hip_device_count(void);
 const char *bwb_hip_last_error(void);
 void bwb_default_params(bwb_params *p);                       /* align.c:22-38 */
@@ -87,9 +94,8 @@ void bwb_default_params(bwb_params *p);                       /* align.c:22-38 *
 /* Creates a context on `device` and builds the device FM-index from the reference's in-memory
  * bwt_t arrays (mg-aligner/bwt.h:19-40, file layout bwt.c:66-82):
  *   hdr = {length, num_words, num_sa, num_occ, sa0_index}, C[17], bwt[num_words], O[num_occ*16].
- * The index is re-laid-out on the GPU into 128-byte rank buckets, in two granularities (128 characters per bucket for locate,
- * 64 for the alignment kernels: 1 + 2 bytes of device memory per BWT character); the host arrays are
- * not referenced after return.  One context per device is the intended use: with the first batch a context sizes its heap
+ * The index is re-laid-out on the GPU into 128-byte rank buckets of 64 BWT characters (2 bytes of device memory per BWT
+ * character); the host arrays are not referenced after return.  One context per device is the intended use: with the first batch a context sizes its heap
  * chunk pool from what the device has free (minus a reserve for the re-run classes and further slots), so a second context
  * on the same device - tests do that - should be given a budget with the environment variable BWB_POOL_GB. */
 int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,

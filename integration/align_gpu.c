@@ -78,6 +78,7 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, sa_intv_list_t *precalc_
 	}
 	bwb_hip_ctx *ctx = NULL;
 	const uint64_t hdr[5] = { BWT->length, BWT->num_words, BWT->num_sa, BWT->num_occ, BWT->sa0_index };
+	if (bwb_hip_abi_version() != BWB_HIP_ABI_VERSION) { printf("align_reads_inexact_gpu: libbwbble_hip.so implements C-ABI version %d, this binding was compiled against %d\n", bwb_hip_abi_version(), BWB_HIP_ABI_VERSION); exit(1); }
 	if (bwb_hip_ctx_create(0, hdr, BWT->C, BWT->bwt, BWT->O, &ctx)) gpu_die("ctx_create");
 
 	/* read_t keeps one malloc per read (io.h:151-185): pack read->seq codes into one [batch][max_len] array per batch */

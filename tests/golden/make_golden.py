@@ -156,9 +156,27 @@ def extras():
         run([REF_BIN, "align"] + flags + ["-t", "1", tfa, sq, os.path.join(HERE, f"short_{name}_t1.aln")])
 
 
+def round4():
+    """Round 4: parameters whose entry scores pass 255 (aln_entry_t.score is an 8-bit field, align.h:104: the break test at
+    inexact_match.c:309 sees the score modulo 256, while aln_t.score - recomputed at :332,348 - is the full int): mismatch-rich reads
+    (4 % substitutions), -n 5 -M 52 -O 60 -E 30 -> 642 heap buckets, five mismatches score 260."""
+    fa = os.path.join(HERE, "toy.fa")
+    tmp = tempfile.mkdtemp(prefix="bwb_golden_")
+    tfa = os.path.join(tmp, "toy.fa")
+    import shutil
+    for ext in ("", ".bwt", ".ann"):
+        shutil.copy(fa + ext, tfa + ext)
+    synth = os.path.join(ROOT, "bwbble_amd", "bin", "bwb_synth")
+    hq = os.path.join(HERE, "himm.fq")
+    run([synth, "reads", fa, hq, "160", "100", "77", "4.0", "10.0", "2.0"])
+    run([REF_BIN, "align", "-n", "5", "-M", "52", "-O", "60", "-E", "30", tfa, hq, os.path.join(HERE, "himm_n5bigpen.aln")])
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--extras":
         return extras()
+    if len(sys.argv) > 1 and sys.argv[1] == "--round4":
+        return round4()
     if not os.path.isdir(REF_SRC):
         sys.exit("reference sources not present; golden vectors can only be regenerated in the build container")
     run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])

@@ -40,7 +40,7 @@ def test_ctypes_mirror_matches_the_header_layout(built, tmp_path):
     import numpy as np
     src = tmp_path / "layout.c"
     fields = {"bwb_params": [n for n, _ in bw.Params._fields_], "bwb_stats": [n for n, _ in bw.Stats._fields_],
-              "bwb_result": [n for n, _ in bw.Result._fields_], "bwb_aln": ["L", "U", "score", "num_mm", "num_gapo", "num_gape", "aln_length", "gap_run"]}
+              "bwb_result": [n for n, _ in bw.Result._fields_], "bwb_aln": ["L", "U", "score", "num_mm", "num_gapo", "num_gape", "reserved", "aln_length", "gap_run"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "bwbble_hip.h"', 'int main(void) {']
     for st, fs in fields.items():
         lines.append(f'printf("{st} %zu\\n", sizeof({st}));')

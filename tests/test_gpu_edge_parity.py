@@ -118,6 +118,10 @@ def test_parked_and_resumed_reads_are_exact(mid, oracle, monkeypatch, env):
     check(ctx, oracle, idx, ["-P", "-n", "2"], seqs, lens)
     check(ctx, oracle, idx, ["-S", "-n", "2"], seqs, lens)
     check(ctx, oracle, idx, ["-n", "3", "-O", "20", "-E", "13", "-e", "2"], seqs[:1500], lens[:1500])
+    # more than 255 heap buckets: best_score has its own word in the save area (round 3 packed it into 8 bits: ADVICE r3), and
+    # entry scores above 255 (the 8-bit wrap of aln_entry_t.score at inexact_match.c:309; 16-bit scores in the hit records)
+    check(ctx, oracle, idx, ["-n", "3", "-M", "40", "-O", "45", "-E", "10"], seqs[:1500], lens[:1500])
+    check(ctx, oracle, idx, ["-n", "5", "-M", "52", "-O", "60", "-E", "30"], seqs[:600], lens[:600])
     ctx.close()
 
 

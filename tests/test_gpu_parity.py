@@ -110,6 +110,15 @@ def test_unsupported_parameters_fail_loudly(toy_ctx):
         toy_ctx.slot_result(3)
 
 
+def test_scores_above_255_match_reference(toy_ctx, golden):
+    """-n 5 -M 52 -O 60 -E 30 on mismatch-rich reads: hits that score above 255 (bwb_aln.score is 16 bits wide since ABI version 2)
+    and the 8-bit wrap of the entry's score in the break test (inexact_match.c:309) - byte-identical to the REAL reference."""
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "himm.fq")))
+    off, alns = toy_ctx.align(bw.params(["-n", "5", "-M", "52", "-O", "60", "-E", "30"]), seqs, lens)
+    assert int(alns["score"].max()) > 255
+    assert bw.aln_bytes(off, alns) == open(os.path.join(golden, "himm_n5bigpen.aln"), "rb").read()
+
+
 def test_penalty_and_score_range_limits(toy_ctx, oracle, golden):
     """Score ranges beyond round 2's 128 heap buckets work (bucket-state rows are sized by the range: here (n+1) M + 2 O + 7 E = 320
     buckets) and equal the oracle; a penalty above 63 is refused (the non-empty buckets are a 64-bit window above the current one)."""

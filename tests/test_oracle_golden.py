@@ -76,3 +76,28 @@ def test_short_reads_see_the_previous_long_reads_dseed(oracle, golden, tmp_path,
     assert open(out, "rb").read() == want
     oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "short.fq"), out, p, fresh_dseed=1)
     assert open(out, "rb").read() != want
+
+
+HIGH_SCORE_FLAGS = ["-n", "5", "-M", "52", "-O", "60", "-E", "30"]
+
+
+def test_scores_above_255_match_reference(oracle, golden, tmp_path):
+    """himm.fq (4 % substitutions) with -n 5 -M 52: 642 heap buckets, five mismatches score 260.  The entry's 8-bit score field
+    wraps (align.h:104; the break test inexact_match.c:309 sees it), the hit's score is the full int (:332,348): the reference's
+    bytes hold scores above 255."""
+    out = str(tmp_path / "o.aln")
+    want = open(os.path.join(golden, "himm_n5bigpen.aln"), "rb").read()
+    n, _, _ = oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, "himm.fq"), out, oracle.params(HIGH_SCORE_FLAGS))
+    assert n == 160
+    assert open(out, "rb").read() == want
+    # (the fixture does exercise the range: some hit's score field exceeds 255)
+    import struct
+    data, pos, top = want, 0, 0
+    while pos < len(data):
+        (ne,) = struct.unpack_from("<i", data, pos); pos += 4
+        for _ in range(ne):
+            score, = struct.unpack_from("<i", data, pos)
+            top = max(top, score)
+            pairs, = struct.unpack_from("<i", data, pos + 4 + 16 + 16)
+            pos += 4 + 16 + 16 + 4 + 4 * pairs
+    assert top > 255

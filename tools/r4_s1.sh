@@ -7,6 +7,6 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4s1; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 bash $R/tools/pmc_mem.sh 3100 10000000 2500000 3 > $O/pmc_mem_c3.log 2>&1; sed -n '/^ms /,$p' $O/pmc_mem_c3.log | head -60
-V=""; for n in laterec lateside priv fnext g2 combo karg kg kgall; do [ -f $R/bwbble_amd/tools_exp/libbwbble_hip_$n.so ] && V="$V $n:bwbble_amd/tools_exp/libbwbble_hip_$n.so"; done
+V=""; for n in laterec lateside g2 combo karg kg kgall; do [ -f $R/bwbble_amd/tools_exp/libbwbble_hip_$n.so ] && V="$V $n:bwbble_amd/tools_exp/libbwbble_hip_$n.so"; done
 # (the karg* builds have never run on a GPU: the A/B lines are their first test; run the GPU test suite with BWB_LIB=<lib> before adopting one)
 AB_TIMEOUT=600 bash $R/tools/ab_bench.sh r4s1_ab "--steps 6 --warmup 2 --no-extras" product $V product2:
