@@ -183,10 +183,10 @@ def main():
     shard_check = None
     if world > 1:
         nbr = (rank + 1) % world
-        ns = min(2000, B)
-        nseqs, nlens = bw.load_fastq_codes(shard(nbr), max_reads=ns)
+        n_chk = min(2000, B)  # (its own name: `ns` is the number of resident slots and goes into the line)
+        nseqs, nlens = bw.load_fastq_codes(shard(nbr), max_reads=n_chk)
         noff, nalns = ctx.align(p, nseqs, nlens)
-        mine = zlib.crc32(bw.aln_bytes(off0[:ns + 1], alns0[:int(off0[ns])]))
+        mine = zlib.crc32(bw.aln_bytes(off0[:n_chk + 1], alns0[:int(off0[n_chk])]))
         theirs = zlib.crc32(bw.aln_bytes(noff, nalns))
         allc = grp.all_gather_pairs(mine, theirs)
         shard_check = all(allc[(r + 1) % world][0] == allc[r][1] for r in range(world))
@@ -218,7 +218,7 @@ def main():
     k_calcd = kernel(vis_calcd, st.ms_calc_d, st.launches_calc_d, st.bucket_loads_calc_d, B * a.steps * 8 * (a.read_len + 2))
     dom_name, dom = ("kl_search", k_search) if st.ms_search >= st.ms_calc_d else ("kl_calc_d", k_calcd)
     traffic, traffic_src = measured_traffic(a, B, dom_name, dom)
-    index_mb = 2 * bwt.length / 1e6  # the alignment kernels' copy: one 128-byte bucket per 64 BWT characters (the octet kernels' copy: per 128)
+    index_mb = 2 * bwt.length / 1e6  # one 128-byte bucket per 64 BWT characters
     scale = {3_100_000_000: "C3 GRCh37-scale", 48_000_000: "C2 chr21-scale"}.get(n_fwd, f"{n_fwd / 1e6:.0f} M-char")
     residency = (f"device index {index_mb:.0f} MB (64-character buckets): Infinity-Cache (256 MB) resident, so this is the fraction of the HBM peak reached from cache"
                  if index_mb <= 256 else f"device index {index_mb:.0f} MB (64-character buckets): larger than the 256 MB Infinity Cache, bucket loads come from HBM")
@@ -235,7 +235,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": dom["device_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom["device_frac"], "traffic": traffic, "traffic_measured_in_run": False, "traffic_source": traffic_src,
                      "traffic_over_device_bytes": round(traffic / dom["device_bytes_per_launch"], 3) if traffic and dom["device_bytes_per_launch"] else None,
-                     "algorithmic_bytes_per_launch": dom["device_bytes_per_launch"],
+                     "device_bytes_per_launch": dom["device_bytes_per_launch"],
+                     "algorithmic_bytes_per_launch": int(dom["visits_per_step"] * a.steps / max(dom["launches"], 1) * ALG_BYTES_PER_VISIT),
                      "kernel_ms_per_launch": dom["ms_per_launch"], "achieved_ref_layout_GBs": dom["ref_layout_GBs"],
                      "kernels": {"kl_search": k_search, "kl_calc_d": k_calcd},
                      "lanes_busy_of_64": round(st.lane_iterations / max(st.wave_iterations, 1), 1),

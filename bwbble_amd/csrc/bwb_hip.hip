@@ -51,7 +51,11 @@ struct DevMem {
 	hipError_t alloc(size_t n) { release(); hipError_t e = hipMalloc(&p, n ? n : 1); if (e == hipSuccess) bytes = n; else p = nullptr; return e; }
 	/* contents are NOT kept; grows by half again at least, so that a stream of slightly larger batches does not reallocate (hipFree
 	 * synchronises the whole device and would stall the queued slices) */
-	hipError_t reserve(size_t n) { return (p && bytes >= n) ? hipSuccess : alloc(p ? std::max(n, bytes + bytes / 2) : n); }
+	hipError_t reserve(size_t n) {
+		if (p && bytes >= n) return hipSuccess;
+		if (p && alloc(std::max(n, bytes + bytes / 2)) == hipSuccess) return hipSuccess;
+		return alloc(n); /* (exactly what is asked for, when half again as much does not fit) */
+	}
 	template <typename T> T *as() const { return (T *)p; }
 };
 struct PinMem {
@@ -283,9 +287,10 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * 32), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * 32);
 	size_t slot_bytes = 0;
 	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * 32);
-	/* (every further slot like the largest so far: a stream needs them all - the heaviest reads of a batch take several slices'
+	/* (every slot still to come like the largest so far: a stream needs them all - the heaviest reads of a batch take several slices'
 	 * time, DESIGN.md section 2.3 - and 8 x 3 GB is little next to the pool) */
-	const size_t more_slots = BWB_MAX_SLOTS - 1;
+	size_t more_slots = 0; /* slots that have no buffers yet (a caller that uploads every slot before the first submit - bench.py - has none left) */
+	for (const Slot &s : c->slots) if (s.d_reads.bytes == 0) more_slots++;
 	const size_t reserve = cls1 + cls2 + more_slots * slot_bytes + ((size_t)4 << 30);
 	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the

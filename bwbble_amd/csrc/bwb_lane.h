@@ -165,7 +165,9 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
 		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oU[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 512 + 64 * r), 16, 0, BWB_GATHER_AUX);
 	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the slices have landed in LDS */
+	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
+	                                       record, the heap entry a pop uncovered, the next list interval: all issued ahead of the gather) */
+	asm volatile("" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
 
@@ -492,6 +494,23 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 template <typename P> __device__ __forceinline__ P pos_enc(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v + (uint64_t)BWB_TEST_POS_BIAS) : v; }
 template <typename P> __device__ __forceinline__ P pos_dec(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v - (uint64_t)BWB_TEST_POS_BIAS) : v; }
 
+/* Loads that are ISSUED AHEAD of the iteration's gather and land under the gather's wait, IN PLACE, for the lanes named by `mask`.  The
+ * destination register holds live values in the other lanes, so the compiler will not let an ordinary load inside a divergent branch write
+ * it: it loads into a scratch register and copies under the exec mask - and the copy waits for the load on the spot, which puts the memory
+ * round trip back in front of the gather.  Here the load is one statement in uniform control flow whose asm narrows the exec mask itself: to
+ * the compiler a plain read-modify-write of `dst`, which stays where it is.  THE RULE: the compiler does not know that the register is in
+ * flight - nothing may read it until a vmcnt(0) wait has been executed (kl_search: the gather's own wait, or the explicit one after it when
+ * no lane of the wave needed a rank).  tools/check_prefetch_regs.py verifies on the ISA of every build that no instruction touches these
+ * registers in between. */
+__device__ __forceinline__ void prefetch128(u32x4 &dst, const void *p, unsigned long long mask) {
+	unsigned long long sv;
+	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
+}
+__device__ __forceinline__ void prefetch32(uint32_t &dst, const void *p, unsigned long long mask) {
+	unsigned long long sv;
+	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dword %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
+}
+
 /* heap entry.  NARROW (max_gapo <= 1): 16 bytes {L lo, U lo, i|mm|go|ge, state|alen<<2|run<<10|L hi<<26|U hi<<29};
  * WIDE: 32 bytes {L, U (64-bit each)} {i|mm|go|ge, state|alen<<8, runs lo, runs hi}.
  * runs: one 16-bit word per gap open: start | len<<8 | isD<<15, 0xFFFF = unused. */
@@ -534,8 +553,20 @@ template <typename P, bool WIDE> struct LHeap {
 	int pX, pGo, pGe;      /* the three penalties (wave-uniform copies of the kernel parameters) */
 	int nbk;               /* number of buckets: a side bucket beyond the score range does not exist */
 	int num_entries;
-	LEntry<P> top;         /* register mirror of the entry on top of bucket cb's memory stack */
-	bool top_valid;
+	/* Register mirror of the TWO entries on top of bucket cb's stack, in the packed form they have in memory (tw: the top - 16 bytes, 32
+	 * when WIDE; sw: the one below it, 16-byte entries only).  Why two, and why packed: a pop takes the top from `tw`; what it uncovers
+	 * comes from `sw` when that is valid, else it is loaded from memory AT ONCE - the load is issued before the iteration's gather and
+	 * lands under the gather's wait; the words are not touched until the next pop unpacks them, so nothing waits for them in between
+	 * (round 3 reloaded the top at the end of the iteration and used it at the start of the next: an exposed memory round trip in every
+	 * iteration of a wave, because some lane always needed it).  When a match child is then pushed - it becomes the top and is popped
+	 * next - the uncovered entry moves down to `sw` instead of being thrown away, and serves the pop after next.  The match child itself
+	 * exists in `tw` only (its slot is reserved, never written); `sw` always has a copy in memory. */
+	u32x4 tw, tw1, sw;
+	bool top_valid, sec_valid;
+	uint32_t cprev;        /* header word .y of the chunk that holds bucket cb's top = the bucket's state before that chunk was started: what
+	                          cst becomes when the chunk's last entry is popped (0 = not known, fetch it then).  Kept in a register so that the
+	                          pop that crosses a chunk boundary (one in 63 per lane, some lane in every other iteration of a wave) does not
+	                          wait for memory; the next chunk's word is fetched at that moment, 63 pops ahead of its use. */
 
 	/* last word of a 16-byte entry: state|aln_length (10 bits), the one gap run (16), bits 32..34 of L and of U (the
 	 * superblock table covers 2^34 BWT characters, bwb_device.h) */
@@ -545,7 +576,7 @@ template <typename P, bool WIDE> struct LHeap {
 		return w;
 	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { fhead = NONE32; pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; stX = stGo = stGe = NONE32; }
+	__device__ __forceinline__ void reset() { fhead = NONE32; pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; sec_valid = false; cprev = 0; stX = stGo = stGe = NONE32; }
 	/* which register holds the state of the side bucket at distance `pen` (a wave-uniform penalty) from cb: 0 = cb itself (zero penalty),
 	 * 1 = stX, 2 = stGo, 3 = stGe.  Equal penalties share the first register of the order X, Go, Ge. */
 	__device__ __forceinline__ int side_of(int pen) const { return pen == 0 ? 0 : (pen == pX ? 1 : (pen == pGo ? 2 : 3)); }
@@ -577,7 +608,7 @@ template <typename P, bool WIDE> struct LHeap {
 		neW >>= d; /* (s > cb: the cached bucket is empty and nothing lies below it) */
 		cb = s; cst = have ? fwd : bstate[s];
 		side_load();
-		top_valid = false;
+		top_valid = false; sec_valid = false; cprev = 0;
 	}
 	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private run of `keep` consecutive
 	 * chunks at the start of its region (a counter: an ordinary read allocates without touching memory); the block's stack
@@ -632,48 +663,79 @@ template <typename P, bool WIDE> struct LHeap {
 		}
 		return st;
 	}
-	__device__ __forceinline__ void store_entry(uint32_t st, const LEntry<P> &e) const {
-		uint4 *p = chunk_ptr(st >> 6);
-		const uint32_t fill = st & 63u;
-		const P L = pos_enc<P>(e.L), U = pos_enc<P>(e.U);
+	/* an entry in the form it has in memory: w0 (and w1 when WIDE) */
+	static __device__ __forceinline__ void pack(P L, P U, uint32_t f, uint32_t sa, uint32_t runsLo, uint32_t runsHi, u32x4 &w0, u32x4 &w1) {
+		L = pos_enc<P>(L); U = pos_enc<P>(U);
 		if (WIDE) {
-			p[fill * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
-			p[fill * 2 + 1] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-		} else p[fill] = make_uint4((uint32_t)L, (uint32_t)U, e.f, pack_w(L, U, e.sa, e.runsLo));
+			w0 = u32x4{ (uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32) };
+			w1 = u32x4{ f, sa, runsLo, runsHi };
+		} else w0 = u32x4{ (uint32_t)L, (uint32_t)U, f, pack_w(L, U, sa, runsLo) };
 	}
-	__device__ __forceinline__ void load_entry(uint32_t st, LEntry<P> &e) const {
-		const uint4 *p = chunk_ptr(st >> 6);
-		const uint32_t fill = st & 63u;
+	static __device__ __forceinline__ void unpack(const u32x4 w0, const u32x4 w1, LEntry<P> &e) {
 		if (WIDE) {
-			const uint4 w0 = p[fill * 2], w1 = p[fill * 2 + 1];
 			e.L = (P)(((uint64_t)w0.y << 32) | w0.x); e.U = (P)(((uint64_t)w0.w << 32) | w0.z);
 			e.f = w1.x; e.sa = w1.y; e.runsLo = w1.z; e.runsHi = w1.w;
-			e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
 		} else {
-			const uint4 w = p[fill];
-			e.L = (P)w.x; e.U = (P)w.y; e.f = w.z; e.sa = w.w & 0x3FFu;
-			if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w.w >> 29) << 32); }
-			e.runsLo = 0xFFFF0000u | ((w.w >> 10) & 0xFFFFu); e.runsHi = 0xFFFFFFFFu;
-			e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
+			e.L = (P)w0.x; e.U = (P)w0.y; e.f = w0.z; e.sa = w0.w & 0x3FFu;
+			if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w0.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w0.w >> 29) << 32); }
+			e.runsLo = 0xFFFF0000u | ((w0.w >> 10) & 0xFFFFu); e.runsHi = 0xFFFFFFFFu;
 		}
+		e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
 	}
-	/* pops the top entry of the cached bucket cb (the best non-empty one) */
-	__device__ __forceinline__ void pop(LEntry<P> &e) {
-		if (top_valid) e = top; else load_entry(cst, e);
-		if ((cst & 63u) == 1u) {
-			uint4 *p = chunk_ptr(cst >> 6);
-			const uint32_t pv = p[0].y;
-			p[0].x = fhead; fhead = cst >> 6; /* chunk goes to the private free list */
+	__device__ __forceinline__ void store_packed(uint32_t st, const u32x4 w0, const u32x4 w1) const {
+		typedef __attribute__((address_space(1))) u32x4 *G4;
+		G4 p = (G4)(uintptr_t)(chunk_ptr(st >> 6) + (st & 63u) * (WIDE ? 2 : 1));
+		p[0] = w0;
+		if (WIDE) p[1] = w1;
+	}
+	/* the entry at state st -> tw (tw1): issued, not waited for - the words are first looked at by the pop that unpacks them */
+	__device__ __forceinline__ void load_top(uint32_t st) {
+		typedef const __attribute__((address_space(1))) u32x4 *G4;
+		G4 p = (G4)(uintptr_t)(chunk_ptr(st >> 6) + (st & 63u) * (WIDE ? 2 : 1));
+		tw = p[0];
+		if (WIDE) tw1 = p[1];
+		top_valid = true;
+	}
+	/* the entry (L, U, f, sa, runs) becomes the top of the cached bucket, in registers only (the caller has reserved its slot and counted it) */
+	__device__ __forceinline__ void set_top(P L, P U, uint32_t f, uint32_t sa, uint32_t runsLo, uint32_t runsHi) { pack(L, U, f, sa, runsLo, runsHi, tw, tw1); top_valid = true; }
+	/* Pops the top entry of the cached bucket cb (the best non-empty one).  n_ld += 1 when an entry is fetched from memory.  What the pop
+	 * uncovers comes from the second mirror register, else from memory: pf_top = its state word, pf_hdr = the chunk whose header word is
+	 * wanted for cprev (NONE32: nothing to fetch) - the caller issues both with prefetch() where the lanes of the wave have met again. */
+	__device__ __forceinline__ void pop(LEntry<P> &e, uint32_t &n_ld, uint32_t &pf_top, uint32_t &pf_hdr) {
+		if (!top_valid) { /* (only after the cached bucket changed, or when something else than a match was pushed on top of it) */
+			load_top(cst); n_ld++;
+			/* this rare load is waited for HERE, inside its branch: a wait after the branches have met again would be executed in every
+			 * iteration, and - vmcnt counts in issue order - would have to be a wait for everything */
+			asm volatile("" :: "v"(tw.x), "v"(tw.y), "v"(tw.z), "v"(tw.w));
+			if (WIDE) asm volatile("" :: "v"(tw1.x), "v"(tw1.y), "v"(tw1.z), "v"(tw1.w));
+		}
+		unpack(tw, tw1, e);
+		asm volatile("" : "+v"(e.L), "+v"(e.U), "+v"(e.f), "+v"(e.sa)); /* (the entry is in its own registers before the load below can be issued into tw) */
+		if ((cst & 63u) == 1u) { /* the last entry of its chunk: the chunk goes to the lane's free list, the bucket continues in the chunk before */
+			typedef __attribute__((address_space(1))) uint32_t *G1;
+			G1 hd = (G1)(uintptr_t)chunk_ptr(cst >> 6);
+			uint32_t pv = cprev;
+			if (pv == 0u) { pv = hd[1]; asm volatile("" :: "v"(pv)); } /* (not known: only the first crossing after the cached bucket changed; waited for inside the branch) */
+			hd[0] = fhead; fhead = cst >> 6;
 			cst = pv;
 			if (pv == NONE32) unmark(cb);
-			top_valid = false;
-		} else {
-			cst--;
-			top_valid = false; /* the new top is fetched at the end of the iteration, unless a match pushed by then has taken its place
-			                      (fetching it here, together with the rank buckets, measured 2 % slower at GRCh37 scale: the sector is
-			                      wasted whenever a match is pushed; tools/r2_probe6.sh) */
-		}
+			cprev = 0u;
+			if (pv != NONE32) pf_hdr = pv >> 6; /* (wanted 63 pops from now) */
+		} else cst--;
+		if (!WIDE && sec_valid) { tw = sw; top_valid = true; sec_valid = false; }
+		else if (cst != NONE32) { pf_top = cst; top_valid = true; n_ld++; }
+		else top_valid = false;
 		num_entries--;
+	}
+	/* issues what pop() asked for (every lane of the wave calls this, in uniform control flow) */
+	__device__ __forceinline__ void prefetch(uint32_t pf_top, uint32_t pf_hdr) {
+		const unsigned long long mt = __ballot(pf_top != NONE32), mh = __ballot(pf_hdr != NONE32);
+		if (mt) {
+			const uint4 *src = pool + (size_t)pf_top * (WIDE ? 2 : 1); /* (a state word is the slot's index in the pool) */
+			prefetch128(tw, src, mt);
+			if (WIDE) prefetch128(tw1, src + 1, mt);
+		}
+		if (mh) prefetch32(cprev, (const uint32_t *)chunk_ptr(pf_hdr) + 1, mh);
 	}
 };
 
@@ -683,18 +745,6 @@ __device__ __forceinline__ uint32_t wave_sum5(uint32_t v) {
 #pragma unroll
 	for (int b = 0; b < 5; b++) t += (uint32_t)__popcll(__ballot((v >> b) & 1u)) << b;
 	return t;
-}
-
-/* stores one heap entry at p and advances p */
-template <typename P, bool WIDE>
-__device__ __forceinline__ void emit_entry(uint4 *&p, P L, P U, uint32_t f, uint32_t sa, uint64_t runs, uint32_t &n_st) {
-	n_st++; /* (per lane and iteration; summed over the wave where the lanes meet again: wave_sum5) */
-	L = pos_enc<P>(L); U = pos_enc<P>(U);
-	if (WIDE) {
-		p[0] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
-		p[1] = make_uint4(f, sa, (uint32_t)runs, (uint32_t)(runs >> 32));
-	} else p[0] = make_uint4((uint32_t)L, (uint32_t)U, f, LHeap<P, WIDE>::pack_w(L, U, sa, (uint32_t)runs));
-	p += WIDE ? 2 : 1;
 }
 
 #define LMODE_POP 0
@@ -740,9 +790,11 @@ enum { H_ITER = 0, H_POP, H_POP_FROM_MIRROR, H_POP_GAPPED, H_PRUNED, H_HIT, H_EX
  * belongs to an earlier slot than the reads its wave starts next, hence the per-lane `myslot` and the slot table. */
 template <typename P, bool WIDE>
 __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
-	/* The kernel arguments that only rare paths use (starting, parking and finishing a read, the hit list, the statistics) are read from
-	 * the kernarg segment where they are used - the pointer goes through an empty asm, so the loads cannot be hoisted out of the loop -
-	 * instead of living in scalar registers across it: the loop keeps about a hundred wave-uniform values and lane masks alive, and what
+	/* The kernel arguments that only rare paths use (starting, parking and finishing a read, the statistics) are read from the kernarg
+	 * segment where they are used - the pointer goes through an empty asm, so the loads cannot be hoisted out of the loop - instead of
+	 * living in scalar registers across it (NOT the hit list's: the end of an exact tail is rare for a lane but happens in most iterations
+	 * of a wave, and a scalar load there is an exposed round trip to the scalar cache - measured 3.7 % slower at GRCh37 scale,
+	 * profiles/r4_ab_steps.txt): the loop keeps about a hundred wave-uniform values and lane masks alive, and what
 	 * does not fit 102 scalar registers is moved to and from VGPR lanes (v_writelane / v_readlane) around every use.  KArgsT mirrors the
 	 * kernel's parameter list (same order, by value: the kernarg segment's layout). */
 	struct KArgsT { DevIndex ix; const SlotDesc *descs; Work wk; KParams kp; LaneScratch sc; unsigned long long *stats; };
@@ -775,13 +827,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	uint32_t slotv = slot;
 #define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
-#define myalns (R_sc(alns) + (size_t)slotv * R_sc(acap) * 2)
+#define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
 #define mysave (R_sc(save) + (size_t)slotv * SAVE_U4)
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
 	const P last_row = (P)(ix.length - 1);
-	constexpr int ESZ = WIDE ? 2 : 1; /* uint4 per heap entry */
 
 	LHeap<P, WIDE> h;
 	const uint32_t region = blockIdx.x % sc.n_regions;
@@ -820,7 +871,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	 * waves fit a SIMD) */
 #define cL e.L
 #define cU e.U
-	h.top = e;
+	h.tw = h.tw1 = h.sw = u32x4{ 0u, 0u, 0u, 0u };
 #define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
 	uint32_t rec_x = 0, rec_y = 0; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
@@ -840,28 +891,24 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const uint4 a0 = mysave[0], a1 = mysave[1], a2 = mysave[2], a3 = mysave[3], a4 = mysave[4], a5 = mysave[5], a6 = mysave[6],
 		            a7 = mysave[7], a8 = mysave[8], a9 = mysave[9], a10 = mysave[10], a11 = mysave[11], a12 = mysave[12], a13 = mysave[13];
 		auto p64 = [](uint32_t lo, uint32_t hi) { return (P)(((uint64_t)hi << 32) | lo); };
+		auto v4 = [](const uint4 a) { return u32x4{ a.x, a.y, a.z, a.w }; };
 		const uint32_t fl = a0.x;
 		exact_mode = ((fl >> 1) & 1u) != 0; cursel = ((fl >> 2) & 1u) != 0; seeding = (fl >> 3) & 1u; nxi_valid = (fl >> 4) & 1u; h.top_valid = (fl >> 5) & 1u;
-		SET_MYSLOT((fl >> 8) & 0xFu);
-		rid = a0.y;
-		SET_LEN(a0.z & 255u); SET_MAX_DIFF((a0.z >> 16) & 255u); SET_BEST_SCORE(a2.x); /* (best_score: up to 1 024 buckets, its own word) */
-		num_best = (int)a0.w;
+		h.sec_valid = (fl >> 6) & 1u;
+		rid = a0.y; rdw = a0.z; num_best = (int)a0.w;
 		n_alns = (int)a1.x; r = (int)a1.y; s = (int)a1.z; curT = (int)a1.w;
-		nx.T = (int)a2.y; cL = p64(a2.z, a2.w);
-		cU = p64(a3.x, a3.y); nx.tL = p64(a3.z, a3.w);
-		nx.tU = p64(a4.x, a4.y); nxi.L = p64(a4.z, a4.w);
-		nxi.U = p64(a5.x, a5.y); e.L = p64(a5.z, a5.w);
-		e.U = p64(a6.x, a6.y); e.f = a6.z; e.sa = a6.w;
-		e.runsLo = a7.x; e.runsHi = a7.y; h.fhead = a7.z;
-		h.pused = a8.x; h.xhead = a8.y; h.xtail = a8.z; h.xcnt = a8.w;
-		h.neW = ((uint64_t)a9.y << 32) | a9.x;
-		h.cb = (int)a10.x; h.cst = a10.y; h.num_entries = (int)a10.z; h.top.f = a10.w;
+		nx.T = (int)a2.x; nxw = a2.y; h.cprev = a2.z; h.fhead = a2.w;
+		e.L = p64(a3.x, a3.y); e.U = p64(a3.z, a3.w); /* (= the tail of the current list in an exact tail) */
+		nx.tL = p64(a4.x, a4.y); nx.tU = p64(a4.z, a4.w);
+		nxi.L = p64(a5.x, a5.y); nxi.U = p64(a5.z, a5.w);
+		e.f = a6.x; e.sa = a6.y; e.runsLo = a6.z; e.runsHi = a6.w;
+		h.pused = a7.x; h.xhead = a7.y; h.xtail = a7.z; h.xcnt = a7.w;
+		h.neW = ((uint64_t)a8.y << 32) | a8.x; h.cb = (int)a8.z; h.cst = a8.w;
 		h.side_load(); /* (the side buckets' states went to memory when the read was parked) */
-		h.top.L = p64(a11.x, a11.y); h.top.U = p64(a11.z, a11.w);
-		h.top.sa = a12.x; h.top.runsLo = a12.y; h.top.runsHi = a12.z; r_vis_s = a12.w;
-		r_vis_a = a13.x; r_pop = a13.y; r_push = a13.z;
-		nxw = mysave[14].x;
-		if (!WIDE) { e.runsHi = ~0u; h.top.runsHi = ~0u; } /* (16-byte entries have one gap run: a constant the compiler can fold) */
+		h.num_entries = (int)a9.x; r_vis_s = a9.y; r_vis_a = a9.z; r_pop = a9.w;
+		r_push = a10.x;
+		h.tw = v4(a11); h.tw1 = v4(a12); h.sw = v4(a13);
+		if (!WIDE) e.runsHi = ~0u; /* (16-byte entries have one gap run: a constant the compiler can fold) */
 		recs = (const uint2 *)(R_descs[rd_myslot].b.dbuf + (size_t)rid * R_descs[rd_myslot].b.dstride);
 		rec_ok = false;
 		active = true;
@@ -932,9 +979,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				}
 				if (!skip && !seeding) {
 					/* heap_push(root) inexact_match.c:281 */
-					LEntry<P> root; root.L = 0; root.U = last_row; root.f = (uint32_t)rd_len; root.sa = 0; root.runsLo = root.runsHi = ~0u;
 					h.cst = h.reserve(NONE32, 1, ovf0);
-					if (!ovf0) { h.cst++; h.store_entry(h.cst, root); h.top = root; h.top_valid = true; h.mark(0); h.num_entries = 1; }
+					if (!ovf0) { h.cst++; h.set_top((P)0, last_row, (uint32_t)rd_len, 0u, ~0u, ~0u); h.store_packed(h.cst, h.tw, h.tw1); h.cprev = NONE32; h.mark(0); h.num_entries = 1; }
 					r_push++;
 				}
 				SET_BEST_SCORE(kp.num_buckets); /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
@@ -954,23 +1000,21 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* (lanes of other waves may be waiting for admission) */
 				auto lo = [](P v) { return (uint32_t)v; };
 				auto hi = [](P v) { return (uint32_t)((uint64_t)v >> 32); };
+				auto u4 = [](const u32x4 a) { return make_uint4(a.x, a.y, a.z, a.w); };
 				const uint32_t fl = 1u | ((exact_mode ? 1u : 0u) << 1) | ((cursel ? 1u : 0u) << 2) | ((seeding ? 1u : 0u) << 3) | ((nxi_valid ? 1u : 0u) << 4) |
-				                    ((h.top_valid ? 1u : 0u) << 5) | (rd_myslot << 8);
-				mysave[0] = make_uint4(fl, rid, (uint32_t)rd_len | ((uint32_t)rd_max_diff << 16), (uint32_t)num_best);
+				                    ((h.top_valid ? 1u : 0u) << 5) | ((h.sec_valid ? 1u : 0u) << 6);
+				mysave[0] = make_uint4(fl, rid, rdw, (uint32_t)num_best);
 				mysave[1] = make_uint4((uint32_t)n_alns, (uint32_t)r, (uint32_t)s, (uint32_t)curT);
-				mysave[2] = make_uint4((uint32_t)rd_best_score, (uint32_t)nx.T, lo(cL), hi(cL));
-				mysave[3] = make_uint4(lo(cU), hi(cU), lo(nx.tL), hi(nx.tL));
-				mysave[4] = make_uint4(lo(nx.tU), hi(nx.tU), lo(nxi.L), hi(nxi.L));
-				mysave[5] = make_uint4(lo(nxi.U), hi(nxi.U), lo(e.L), hi(e.L));
-				mysave[6] = make_uint4(lo(e.U), hi(e.U), e.f, e.sa);
-				mysave[7] = make_uint4(e.runsLo, e.runsHi, h.fhead, 0u);
-				mysave[8] = make_uint4(h.pused, h.xhead, h.xtail, h.xcnt);
-				mysave[9] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), 0u, 0u);
-				mysave[10] = make_uint4((uint32_t)h.cb, h.cst, (uint32_t)h.num_entries, h.top.f);
-				mysave[11] = make_uint4(lo(h.top.L), hi(h.top.L), lo(h.top.U), hi(h.top.U));
-				mysave[12] = make_uint4(h.top.sa, h.top.runsLo, h.top.runsHi, r_vis_s);
-				mysave[13] = make_uint4(r_vis_a, r_pop, r_push, 0u);
-				mysave[14] = make_uint4(nxw, 0u, 0u, 0u);
+				mysave[2] = make_uint4((uint32_t)nx.T, nxw, h.cprev, h.fhead);
+				mysave[3] = make_uint4(lo(e.L), hi(e.L), lo(e.U), hi(e.U));
+				mysave[4] = make_uint4(lo(nx.tL), hi(nx.tL), lo(nx.tU), hi(nx.tU));
+				mysave[5] = make_uint4(lo(nxi.L), hi(nxi.L), lo(nxi.U), hi(nxi.U));
+				mysave[6] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
+				mysave[7] = make_uint4(h.pused, h.xhead, h.xtail, h.xcnt);
+				mysave[8] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), (uint32_t)h.cb, h.cst);
+				mysave[9] = make_uint4((uint32_t)h.num_entries, r_vis_s, r_vis_a, r_pop);
+				mysave[10] = make_uint4(r_push, 0u, 0u, 0u);
+				mysave[11] = u4(h.tw); mysave[12] = u4(WIDE ? h.tw1 : h.tw); mysave[13] = u4(h.sw);
 				h.side_flush();
 			}
 			parked = active;
@@ -980,6 +1024,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (!__any(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
 
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
+		uint32_t ld_cnt = 0; /* heap entries this lane fetches from memory in this iteration */
+		uint32_t pf_top = NONE32, pf_hdr = NONE32; /* what LHeap::pop wants fetched ahead of the gather */
 		P iL = 0, iU = 0;
 		int widx = 0;
 		n_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_iter + (uint32_t)__popcll(__ballot(active)))); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
@@ -998,7 +1044,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					if (a.x == (uint32_t)L && a.y == (uint32_t)((uint64_t)L >> 32) && a.z == (uint32_t)U && a.w == (uint32_t)((uint64_t)U >> 32)) return;
 				}
 			}
-			if (n_alns >= (int)R_sc(acap)) { ovf = true; return; }
+			if (n_alns >= (int)sc.acap) { ovf = true; return; }
 			myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
 			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), e.runsLo, e.runsHi); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
 			n_alns++;
@@ -1015,7 +1061,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #ifdef BWB_HIST
 				h_mirror = h.top_valid;
 #endif
-				h.pop(e); /* heap_pop :594-610: the top of the best bucket, usually straight from its register mirror */
+				h.pop(e, ld_cnt, pf_top, pf_hdr); /* heap_pop :594-610: the top of the best bucket from its register mirror; what it uncovers is fetched now, under the gather */
 				is_group = (e.sa & 3u) == (uint32_t)STATE_GROUP;
 				/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the
 				 * group's last child, which happens in the next iteration, once the children are in place */
@@ -1041,9 +1087,16 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			widx = r + 1;
 			if (s == curT - 1) { iL = cL; iU = cU; }
 			else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous step */
-			else { const Intv<P> v = (lbase + (cursel ? lcap : 0))[s]; iL = v.L; iU = v.U; }
+			else { /* (only the iteration after a resume: waited for inside the branch, see LHeap::pop) */
+				const Intv<P> v = (lbase + (cursel ? lcap : 0))[s]; iL = v.L; iU = v.U;
+				asm volatile("" :: "v"(iL), "v"(iU));
+			}
 			need_rank = true;
+			/* the interval of the step's NEXT iteration, when it is one of the list in memory (not its tail, which is in registers): fetched
+			 * now, under this iteration's gather (round 3 fetched it at the end of the iteration and used it at the start of the next) */
+			if (s + 1 < curT - 1) nxi = (lbase + (cursel ? lcap : 0))[s + 1];
 		}
+		h.prefetch(pf_top, pf_hdr); /* (the lanes have met again: see prefetch128) */
 
 #ifdef BWB_HIST
 		HIST(H_POP, active && !exact_mode && (from_pop || finish)); HIST(H_POP_GAPPED, from_pop && ((e.f >> 16) != 0)); HIST(H_POP_FROM_MIRROR, from_pop && h_mirror);
@@ -1069,10 +1122,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 		u32x2_t rec_new = { 0u, 0u };
 		bool rec_fresh = false;
-		/* The interval of this iteration comes from a load of the previous one (the reloaded heap top, the next list interval): the wave
-		 * waits for it HERE, before the record load is issued - vmcnt counts in issue order, and a wait placed after the record load (where
-		 * the interval is first used) would wait for the record as well. */
-		asm volatile("" :: "v"(iL), "v"(iU));
 		if (want_rec) {
 			if (!exact_mode) rec_ok = false; /* (a popped entry has its own position) */
 			if (!rec_ok) { /* (every interval of a multi-interval exact step reads the same record: one step in four at GRCh37 scale) */
@@ -1092,6 +1141,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		KidCtx<P> kc;
 		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
+		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32 in LHeap::pop) has landed, also when no lane needed a rank */
 		if (rec_fresh) { rec_x = rec_new.x; rec_y = rec_new.y; }
 		if (want_rec) {
 			wd = rec_x & 0xFFFFu; ws = rec_x >> 16;
@@ -1117,20 +1167,24 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (from_pop && is_group) {
 			/* ---- a deletion group has reached the top of its bucket: its children take its place ---- */
 			const int n = __popc(ne);
-			const uint32_t st0 = h.reserve(h.cst, n, ovf);
+			const uint32_t cst_old = h.cst;
+			const uint32_t st0 = h.reserve(cst_old, n, ovf);
 			if (!ovf && n > 0) {
-				uint4 *p0 = h.chunk_ptr(st0 >> 6) + ((st0 & 63u) + 1) * ESZ;
+				if (st0 != cst_old) h.cprev = cst_old; /* (a new chunk was started: its header names the state before it) */
 				const uint32_t sd = (e.sa & ~3u) | (uint32_t)STATE_D;
-				const uint64_t eruns = ((uint64_t)e.runsHi << 32) | e.runsLo;
-				uint32_t gm = ne;
+				uint32_t sx = st0, gm = ne;
 				while (gm) {
 					const int j = __ffs((int)gm) - 1;
 					gm &= gm - 1;
-					kid(j, h.top.L, h.top.U);
-					if (gm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, e.f, sd, eruns, st_cnt); /* (the last child is popped next: the register mirror is its only copy) */
+					P cl, cu;
+					kid(j, cl, cu);
+					u32x4 w0, w1;
+					h.pack(cl, cu, e.f, sd, e.runsLo, e.runsHi, w0, w1);
+					if (gm) { h.store_packed(++sx, w0, w1); st_cnt++; if (!WIDE) h.sw = w0; }
+					else { h.tw = w0; h.tw1 = w1; } /* (the last child is popped next: the register mirror is its only copy) */
 				}
-				h.top.f = e.f; h.top.sa = sd; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi;
-				h.cst = st0 + (uint32_t)n; h.mark(e_score); h.top_valid = true;
+				h.top_valid = true; h.sec_valid = !WIDE && n >= 2; /* (n == 1 cannot happen: a single deletion child is stored as itself) */
+				h.cst = st0 + (uint32_t)n; h.mark(e_score);
 			}
 		} else if (from_pop) {
 			const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
@@ -1207,7 +1261,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const int k1 = (tX == 1 ? nX : 0) + (tG == 1 ? nG : 0);
 					const int k2 = tG == 2 ? nG : 0;
 					STAMP(9);
-					uint32_t st0 = h.reserve(h.cst, k0, ovf);
+					const uint32_t cst_old = h.cst;
+					uint32_t st0 = h.reserve(cst_old, k0, ovf);
 					const uint32_t stX = h.stX, vGo = h.stGo, vGe = h.stGe, stG = wG == 2 ? vGo : vGe;
 					uint32_t st1 = h.reserve(stX, k1, ovf);
 					uint32_t st2 = h.reserve(stG, k2, ovf);
@@ -1227,44 +1282,57 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 							gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
 							gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
 						} else gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
-						/* next free slot of every target bucket */
-						uint4 *p0 = h.chunk_ptr(st0 >> 6) + ((st0 & 63u) + 1) * ESZ;
-						uint4 *p1 = h.chunk_ptr(st1 >> 6) + ((st1 & 63u) + 1) * ESZ;
-						uint4 *p2 = h.chunk_ptr(st2 >> 6) + ((st2 & 63u) + 1) * ESZ;
-						bool top_ok = false; /* does h.top mirror the last entry stored on bucket sc0? */
+						/* the slot last used on every target bucket (a state word is also the slot's index in the pool: chunk << 6 | fill) */
+						uint32_t s0 = st0, s1 = st1, s2 = st2;
+						auto emit = [&](uint32_t &sx, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+							u32x4 w0, w1;
+							h.pack(L, U, f, sa, (uint32_t)runs, (uint32_t)(runs >> 32), w0, w1);
+							h.store_packed(++sx, w0, w1);
+							st_cnt++; /* (per lane and iteration; summed over the wave where the lanes meet again: wave_sum5) */
+						};
+						bool top_ok = false; /* does the register mirror hold the last entry pushed on bucket sc0? */
 						STAMP(11);
 						{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
 						   * holds the parent's interval (a single deletion child is stored as itself) */
-							uint4 *pg = tG == 0 ? p0 : (tG == 1 ? p1 : p2);
-							if (nIns) emit_entry<P, WIDE>(pg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, st_cnt);
+							uint32_t sg = tG == 0 ? s0 : (tG == 1 ? s1 : s2);
+							if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i);
 							const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
-							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit_entry<P, WIDE>(pg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, st_cnt); }
-							else if (nDel) emit_entry<P, WIDE>(pg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, st_cnt);
-							if (tG == 0) p0 = pg; else if (tG == 1) p1 = pg; else p2 = pg;
+							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d); }
+							else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d);
+							if (tG == 0) s0 = sg; else if (tG == 1) s1 = sg; else s2 = sg;
 						}
 						STAMP(12);
 						const uint32_t sm = (uint32_t)STATE_M | (alen1 << 2);
 						if (kp.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
-							uint4 *px = tX == 1 ? p1 : p0;
+							uint32_t sxm = tX == 1 ? s1 : s0;
 							uint32_t xm = mism;
 							while (xm) {
 								const int j = __ffs((int)xm) - 1;
 								xm &= xm - 1;
 								P cl, cu;
 								kid(j, cl, cu);
-								emit_entry<P, WIDE>(px, cl, cu, f_mis, sm, eruns, st_cnt);
+								emit(sxm, cl, cu, f_mis, sm, eruns);
 							}
-							if (tX == 1) p1 = px; else p0 = px;
+							if (tX == 1) s1 = sxm; else s0 = sxm;
+							/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket being
+							 * popped): the register mirror is its only copy, its slot is reserved but never written.  The entry below it - the
+							 * match child before it, or with a single child what the pop uncovered, when nothing else went on top of that -
+							 * stays in the second mirror register. */
+							const u32x4 unc = h.tw; /* (what the pop uncovered: from the second mirror register, or on its way from memory) */
+							bool sec_ok = h.top_valid && k0 == 1;
+							u32x4 sec = unc;
 							uint32_t mm = matchm;
 							while (mm) {
 								const int j = __ffs((int)mm) - 1;
 								mm &= mm - 1;
-								kid(j, h.top.L, h.top.U);
-								/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket
-								 * being popped): the register mirror is its only copy, its slot is reserved but never written. */
-								if (mm) emit_entry<P, WIDE>(p0, h.top.L, h.top.U, f_match, sm, eruns, st_cnt);
+								P cl, cu;
+								kid(j, cl, cu);
+								u32x4 w0, w1;
+								h.pack(cl, cu, f_match, sm, e.runsLo, e.runsHi, w0, w1);
+								if (mm) { h.store_packed(++s0, w0, w1); st_cnt++; sec = w0; sec_ok = true; }
+								else { h.tw = w0; h.tw1 = w1; }
 							}
-							if (matchm) { h.top.f = f_match; h.top.sa = sm; h.top.runsLo = e.runsLo; h.top.runsHi = e.runsHi; top_ok = true; }
+							if (matchm) { top_ok = true; if (!WIDE) { h.sw = sec; h.sec_valid = sec_ok; } }
 						} else { /* mm_score == 0: one bucket, interleaved in code order */
 							uint32_t am = mgrp;
 							while (am) {
@@ -1272,12 +1340,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								am &= am - 1;
 								P cl, cu;
 								kid(j, cl, cu);
-								emit_entry<P, WIDE>(p0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns, st_cnt);
+								emit(s0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
 							}
 						}
 						STAMP(13);
 						h.num_entries += nGc + nX + n0;
-						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; }
+						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; if (!top_ok) h.sec_valid = false; if (st0 != cst_old) h.cprev = cst_old; }
 						if (k1 > 0) { h.stX = st1 + (uint32_t)k1; h.mark(scX); }
 						if (k2 > 0) { const uint32_t v = st2 + (uint32_t)k2; if (wG == 2) h.stGo = v; else h.stGe = v; h.mark(scG); }
 					}
@@ -1307,16 +1375,20 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap, ovf);
 				}
 				s++;
+				bool swapped = false;
 				if (!ovf && s >= curT) {
+					swapped = true;
 					cursel = !cursel; curT = nx.T; cL = nx.tL; cU = nx.tU;
 					nx.T = 0; s = 0; rec_ok = false;
 					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < (seeding ? rd_len - PRECALC_LEN : 0)) exact_done = true; }
 				}
-				/* the interval of the next step, when it is not the list's tail (which is in registers): on its way now */
+				/* the interval of the next iteration, when it is not the list's tail (which is in registers): within a step it is on its way
+				 * since the start of this iteration; the first interval of a NEW list (written by this very step: it comes back from L2) is
+				 * fetched now */
 				nxi_valid = !ovf && !exact_done && s != curT - 1;
-				if (nxi_valid) nxi = (lbase + (cursel ? lcap : 0))[s];
+				if (nxi_valid && swapped) nxi = (lbase + (cursel ? lcap : 0))[s];
 			}
 			STAMP(6);
 			if (exact_done && !ovf && seeding) {
@@ -1324,16 +1396,17 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				exact_mode = false; seeding = false;
 				if (curT == 0) finish = true;
 				else {
-					LEntry<P> ent; ent.f = (uint32_t)(rd_len - PRECALC_LEN); ent.sa = (uint32_t)STATE_M | ((uint32_t)PRECALC_LEN << 2); ent.runsLo = ent.runsHi = ~0u;
-					ent.L = ent.U = 0;
+					const uint32_t ent_f = (uint32_t)(rd_len - PRECALC_LEN), ent_sa = (uint32_t)STATE_M | ((uint32_t)PRECALC_LEN << 2);
 					uint32_t st = h.cst; /* bucket 0 of the empty heap */
 					for (int k = 0; k < curT && !ovf; k++) {
-						if (k == curT - 1) { ent.L = cL; ent.U = cU; }
-						else { const Intv<P> v = (lbase + (cursel ? lcap : 0))[k]; ent.L = v.L; ent.U = v.U; }
-						st = h.reserve(st, 1, ovf);
-						if (!ovf) { st++; h.store_entry(st, ent); }
+						P iL2, iU2;
+						if (k == curT - 1) { iL2 = cL; iU2 = cU; }
+						else { const Intv<P> v = (lbase + (cursel ? lcap : 0))[k]; iL2 = v.L; iU2 = v.U; }
+						const uint32_t st_old = st;
+						st = h.reserve(st_old, 1, ovf);
+						if (!ovf) { if (st != st_old) h.cprev = st_old; st++; h.set_top(iL2, iU2, ent_f, ent_sa, ~0u, ~0u); h.store_packed(st, h.tw, h.tw1); }
 					}
-					if (!ovf) { h.cst = st; h.mark(0); h.num_entries = curT; h.top = ent; h.top_valid = true; r_push += (uint32_t)curT; }
+					if (!ovf) { h.cst = st; h.mark(0); h.num_entries = curT; h.sec_valid = false; r_push += (uint32_t)curT; }
 				}
 			} else if (exact_done && !ovf) {
 				exact_mode = false;
@@ -1355,7 +1428,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						const Intv<P> *lst = lbase + (cursel ? lcap : 0);
 						int k = 0;
 						if (e_go == 0) { /* no duplicate check (align.c:273-280 applies to gapped entries): four list loads in flight at a time */
-							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)R_sc(acap); k += 4) {
+							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)sc.acap; k += 4) {
 								const Intv<P> v0 = lst[k], v1 = lst[k + 1], v2 = lst[k + 2], v3 = lst[k + 3];
 								add_aln(v0.L, v0.U, e_score, alen2); add_aln(v1.L, v1.U, e_score, alen2);
 								add_aln(v2.L, v2.U, e_score, alen2); add_aln(v3.L, v3.U, e_score, alen2);
@@ -1373,14 +1446,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 
 		STAMP(15);
-		HIST(H_TOP_RELOAD, active && !h.top_valid && h.cst != NONE32);
-		const bool reload = active && !h.top_valid && h.cst != NONE32;
-		n_eld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_eld + (uint32_t)__popcll(__ballot(reload))));
+		HIST(H_TOP_RELOAD, ld_cnt != 0);
+		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
+		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
+		n_eld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_eld + wave_sum5(ld_cnt)));
 		n_est = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_est + wave_sum5(st_cnt > 31u ? 31u : st_cnt)));
-		if (reload) { /* prefetch the top of the cached bucket: needed at the earliest by the next pop */
-			h.load_entry(h.cst, h.top);
-			h.top_valid = true;
-		}
 		STAMP(5);
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);

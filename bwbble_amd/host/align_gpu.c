@@ -198,8 +198,10 @@ int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_
 		char *preFname = (char *)malloc(L);
 		snprintf(preFname, L, "%s.pre", fastaFname);
 		FILE *pf = fopen(preFname, "r");
-		if (pf) fclose(pf);
-		else {
+		if (pf) { /* load_precalc_sa_intervals (align.c:226-238) would read it: here only its shape is checked (precalc.c) */
+			fclose(pf);
+			if (check_precalc_file(preFname)) fprintf(stderr, "warning: %s is not a complete table of 16777216 interval lists (a run of the reference would fail on it): delete it to have it rebuilt\n", preFname);
+		} else {
 			t = wall();
 			precalc_sa_intervals(BWT, params, preFname);
 			printf("Total pre-calculated intervals time: %.2f sec\n", wall() - t);

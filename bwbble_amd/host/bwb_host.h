@@ -89,6 +89,7 @@ int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_interva
 
 /* precalc.c */
 void precalc_sa_intervals(bwt_t *BWT, const aln_params_t *params, const char *preFname); /* align.c:200-224: writes <fasta>.pre */
+int check_precalc_file(const char *preFname); /* the walk of load_precalc_sa_intervals (align.c:226-238) over an existing table: 0 = complete */
 
 /* sam.c */
 void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFname, int is_multiref, int max_diff, int n_gpus); /* align.c:494-556 */

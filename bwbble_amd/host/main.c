@@ -21,7 +21,7 @@ static int align_usage(void) {
 	printf("         k    maximum number of differences in the seed (default: 2)\n         o    maximum number of gap opens (default: 1)\n");
 	printf("         e    maximum number of gap extends (default: 6) \n         t    accepted for compatibility, ignored (the GPU path has no host threads knob)\n");
 	printf("         g    number of GPUs to use (default: 1; more than are present is an error)\n");
-	printf("         S    align with a single-genome reference\n         P    use pre-calculated partial alignment results (computed on the fly; no .pre file is read or written)\n\n");
+	printf("         S    align with a single-genome reference\n         P    use pre-calculated partial alignment results (the GPU computes them per read; <fasta>.pre is written like the reference does when it is missing, and only checked for completeness when present)\n\n");
 	return 1;
 }
 

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Developer tool + CPU test helper: verifies on the ISA that the registers written by the in-place prefetches of kl_search
+(prefetch128 / prefetch32 in bwb_lane.h: global loads issued ahead of the gather by an asm that narrows the exec mask) are not touched
+by any instruction until a vmcnt(0) wait has been executed.
+
+The compiler does not know that those registers are in flight: a copy, a spill or a use it placed between the load and the wait would
+read bytes that have not arrived.  The source is written so that there is none (the loaded values are first looked at after the
+gather's wait); this script proves it for the code hipcc actually generated, for every kl_search instantiation:
+
+  * every prefetch site  s_and_saveexec_b64 / global_load_dword[x4] vD, ... / s_mov_b64 exec  is found;
+  * from there the code is followed along fall-through and branch edges (both ways of a conditional branch) until an
+    `s_waitcnt` with vmcnt(0) is met on the path; any instruction on the way that names a register of vD (as a source or as a
+    destination) is an error - except the other prefetch sites' own loads into their own registers.
+
+usage: check_prefetch_regs.py [-D<flag> ...]      exit code 0 = clean; prints one line per kernel"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "bwbble_amd", "csrc", "bwb_hip.hip")
+
+
+def compile_isa(flags):
+    d = tempfile.mkdtemp(prefix="isa_")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-Wno-unused-value",
+           "--save-temps", "-o", os.path.join(d, "lib.so"), SRC] + flags
+    subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.join(d, "bwb_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def vregs(text):
+    """all VGPR numbers an operand string names: v12, v[38:41]"""
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def is_vm0_wait(ins):
+    if not ins.startswith("s_waitcnt"):
+        return False
+    m = re.search(r"vmcnt\((\d+)\)", ins)
+    if m:
+        return int(m.group(1)) == 0
+    m = re.match(r"s_waitcnt\s+(0x[0-9a-fA-F]+|\d+)\s*$", ins)  # raw immediate: vmcnt = bits 3:0 and 15:14
+    if m:
+        v = int(m.group(1), 0)
+        return (v & 0xF) == 0 and ((v >> 14) & 3) == 0
+    return False
+
+
+def check_kernel(name, body):
+    """body: list of stripped lines (labels and instructions) of one kernel"""
+    ins, labels = [], {}
+    for ln in body:
+        if not ln or ln.startswith(";") or ln.startswith(".loc") or ln.startswith(".Ltmp") or ln.startswith(".cfi") or ln.startswith(".p2align"):
+            continue
+        m = re.match(r"^(\.LBB\w+):", ln)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        if ln.startswith("."):
+            continue
+        ins.append(ln.split(";")[0].strip())
+    sites = [i for i in range(len(ins) - 2) if ins[i].startswith("s_and_saveexec_b64") and ins[i + 1].startswith("global_load_dword") and ins[i + 2].startswith("s_mov_b64 exec")]
+    site_loads = {i + 1 for i in sites}
+    errors = []
+    for i in sites:
+        dst = vregs(ins[i + 1].split(",")[0])
+        seen, work = set(), [i + 3]
+        while work:
+            pc = work.pop()
+            while pc < len(ins) and pc not in seen:
+                seen.add(pc)
+                t = ins[pc]
+                if is_vm0_wait(t):
+                    break
+                if pc not in site_loads or vregs(t.split(",")[0]) & dst:
+                    hit = vregs(t) & dst
+                    if hit and not (pc in site_loads and not (vregs(t.split(",")[0]) & dst)):
+                        errors.append(f"{name}: `{t}` touches v{sorted(hit)} of the prefetch `{ins[i + 1]}` before a vmcnt(0) wait")
+                        break
+                m = re.match(r"^(s_cbranch_\w+|s_branch)\s+(\.LBB\w+)", t)
+                if m:
+                    if m.group(2) in labels:
+                        work.append(labels[m.group(2)])
+                    if m.group(1) == "s_branch":
+                        break
+                if t.startswith("s_endpgm"):
+                    break
+                pc += 1
+    return len(sites), errors
+
+
+def main():
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    path = compile_isa(flags)
+    cur, kernels = None, {}
+    for ln in open(path):
+        m = re.match(r"^(_Z\w*kl_search\w*):", ln)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        if cur:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+                continue
+            kernels[cur].append(ln.strip())
+    bad = 0
+    for k, body in kernels.items():
+        n, errs = check_kernel(k, body)
+        print(f"{k}: {n} prefetch site(s), {'OK' if not errs else 'HAZARD'}")
+        for e in errs:
+            print("   " + e)
+        bad += len(errs)
+        if n == 0:
+            print("   no prefetch site found: the check is vacuous")
+            bad += 1
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
