@@ -1,0 +1,52 @@
+"""CPU-only (hipcc cross-compiles): properties of the generated gfx950 code that the design depends on.
+
+  * kl_search keeps three waves per SIMD (at most 168 VGPRs) and the headline instantiation <u64 positions, 16-byte entries> has no
+    scratch and no VGPR spill;
+  * the registers written by the in-place prefetches (bwb_lane.h: prefetch128 / prefetch32) are not touched before a vmcnt(0) wait
+    (tools/check_prefetch_regs.py)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def compiled():
+    import check_prefetch_regs as cpr
+    return cpr.check_all()
+
+
+def test_prefetched_registers_are_not_read_before_the_wait(compiled):
+    res, _ = compiled
+    assert len(res) == 4  # <u32|u64> x <16|32-byte entries>
+    for k, (sites, errs) in res.items():
+        assert sites >= 2, k  # the uncovered heap entry and the chunk header word
+        assert not errs, errs
+
+
+def test_search_kernel_register_budget(compiled):
+    _, remarks = compiled
+    ks = {k: v for k, v in remarks.items() if "kl_search" in k}
+    assert len(ks) == 4
+    for k, ru in ks.items():
+        assert ru["Occupancy"] >= 3 and ru["VGPRs"] <= 168, (k, ru)
+    head = [v for k, v in ks.items() if "kl_searchImLb0E" in k][0]  # 64-bit positions (GRCh37 scale), 16-byte heap entries (-o <= 1)
+    assert head["ScratchSize"] == 0 and head["VGPRs Spill"] == 0, head
+
+
+def test_checker_sees_a_hazard():
+    """the checker is not vacuous: a register that is read between the prefetch and the wait is reported"""
+    import check_prefetch_regs as cpr
+    body = ["s_and_saveexec_b64 s[12:13], s[10:11]", "global_load_dwordx4 v[38:41], v[50:51], off", "s_mov_b64 exec, s[12:13]",
+            "v_add_u32_e32 v1, v2, v3", "v_mov_b32_e32 v7, v40", "s_waitcnt vmcnt(0)"]
+    n, errs = cpr.check_kernel("k", body)
+    assert n == 1 and len(errs) == 1
+    body[4] = "v_mov_b32_e32 v7, v42"
+    assert cpr.check_kernel("k", body) == (1, [])
+    body[5] = "s_waitcnt vmcnt(1)"  # not a full wait: the scan runs on to the end without finding one, but nothing touches the registers
+    body.append("s_cbranch_execz .LBB0_1"); body.append(".LBB0_1:"); body.append("v_mov_b32_e32 v8, v39"); body.append("s_endpgm")
+    n, errs = cpr.check_kernel("k", body)
+    assert n == 1 and len(errs) == 1

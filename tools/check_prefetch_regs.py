@@ -23,12 +23,44 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "bwbble_amd", "csrc", "bwb_hip.hip")
 
 
-def compile_isa(flags):
+def compile_isa(flags, remarks=None):
+    """compiles the library with --save-temps; returns the path of the gfx950 assembly.  remarks: a dict that receives, per kernel symbol,
+    the compiler's resource-usage remarks (VGPRs, ScratchSize, SGPRs Spill, VGPRs Spill, Occupancy)"""
     d = tempfile.mkdtemp(prefix="isa_")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-Wno-unused-value",
-           "--save-temps", "-o", os.path.join(d, "lib.so"), SRC] + flags
-    subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+           "--save-temps", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "lib.so"), SRC] + flags
+    r = subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    if remarks is not None:
+        cur = None
+        for ln in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                cur = m.group(1)
+                remarks[cur] = {}
+                continue
+            m = re.search(r"\s{2,}([A-Za-z][A-Za-z ]*?)(?: \[[^\]]*\])?: (\d+) \[-Rpass", ln)
+            if m and cur:
+                remarks[cur][m.group(1).strip()] = int(m.group(2))
     return os.path.join(d, "bwb_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def check_all(flags=()):
+    """-> ({kernel: (sites, [errors])}, {kernel: resource remarks}) for every kl_search instantiation"""
+    remarks = {}
+    path = compile_isa(list(flags), remarks)
+    cur, kernels = None, {}
+    for ln in open(path):
+        m = re.match(r"^(_Z\w*kl_search\w*):", ln)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        if cur:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+                continue
+            kernels[cur].append(ln.strip())
+    return {k: check_kernel(k, body) for k, body in kernels.items()}, remarks
 
 
 def vregs(text):
@@ -99,23 +131,11 @@ def check_kernel(name, body):
 
 def main():
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
-    path = compile_isa(flags)
-    cur, kernels = None, {}
-    for ln in open(path):
-        m = re.match(r"^(_Z\w*kl_search\w*):", ln)
-        if m:
-            cur = m.group(1)
-            kernels[cur] = []
-            continue
-        if cur:
-            if ln.startswith(".Lfunc_end"):
-                cur = None
-                continue
-            kernels[cur].append(ln.strip())
+    res, remarks = check_all(flags)
     bad = 0
-    for k, body in kernels.items():
-        n, errs = check_kernel(k, body)
-        print(f"{k}: {n} prefetch site(s), {'OK' if not errs else 'HAZARD'}")
+    for k, (n, errs) in res.items():
+        ru = remarks.get(k, {})
+        print(f"{k}: {n} prefetch site(s), {'OK' if not errs else 'HAZARD'} | VGPRs {ru.get('VGPRs')} scratch {ru.get('ScratchSize')} B/lane, spills: {ru.get('SGPRs Spill')} SGPR, {ru.get('VGPRs Spill')} VGPR, {ru.get('Occupancy')} waves/SIMD")
         for e in errs:
             print("   " + e)
         bad += len(errs)
