@@ -177,8 +177,19 @@ static int fetch(bwb_hip_ctx *c, void *dst, const void *src, size_t n) {
 	return BWB_OK;
 }
 
+/* waits until the caller's loader has brought the first `need` 128-character blocks of the index into the host arrays */
+static void wait_blocks(const volatile uint64_t *ready, uint64_t need) {
+	if (!ready) return;
+	while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) < need) { struct timespec ts = { 0, 200000 }; nanosleep(&ts, nullptr); }
+}
+
 extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
                                   const uint64_t *O, bwb_hip_ctx **out) {
+	return bwb_hip_ctx_create_streamed(device, hdr, C, bwt, O, nullptr, out);
+}
+
+extern "C" int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                                           const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out) {
 	if (!hdr || !C || !bwt || !O || !out) return fail(BWB_E_ARG, "ctx_create: null argument");
 	const uint64_t length = hdr[0], num_words = hdr[1], num_occ = hdr[3];
 	const uint64_t nblk = (length + 127) / 128;
@@ -204,16 +215,12 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	if (getenv("BWB_SLICE_ITERS")) c->slice_iters = (uint32_t)strtoul(getenv("BWB_SLICE_ITERS"), nullptr, 10);
 	c->force_slices = getenv("BWB_FORCE_SLICES") != nullptr || c->slice_iters != 0;
 
-	/* superblock base table */
+	/* superblock base table (a superblock's row is filled in when the upload below reaches its first block: with a streamed index the
+	 * host arrays are still being read) */
 	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
 	memset(&c->ix, 0, sizeof(c->ix));
-	for (uint64_t sb = 0; sb < nsb; sb++) {
-		const uint64_t blk = sb << BWB_SB_SHIFT;
-		const uint32_t first = bwt[blk * 16] >> 28;
-		for (int j = 0; j < 16; j++) sbcount[sb * 16 + j] = O[blk * 16 + j] - ((first == (uint32_t)j && !(j == 0 && blk * 128 == hdr[4])) ? 1 : 0);
-	}
 	for (uint64_t sb = 0; sb < BWB_NSB_MAX; sb++)
-		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
+		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j];
 	for (int j = 0; j < 16; j++) { c->ix.base[BWB_ROW_NEG][j] = C[j]; c->ix.base[BWB_ROW_END][j] = C[j + 1]; }
 	c->ix.buckets = c->d_buckets.as<uint4>();
 	c->ix.length = length;
@@ -234,12 +241,22 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 		HIPCHK(ev_k[t].create());
 	}
 	HIPCHK(d_sbc.alloc(sbcount.size() * 8));
-	HIPCHK(hipMemcpyAsync(d_sbc.p, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
 	int t = 0;
 	for (uint64_t b0 = 0; b0 < nblk; b0 += CH, t ^= 1) {
 		const uint64_t nb = std::min(CH, nblk - b0);
 		const uint64_t w0 = b0 * 16, nw = std::min(nb * 16, num_words - w0);
+		wait_blocks(blocks_ready, b0 + nb); /* streamed: the loader has read this chunk of the .bwt file */
+		for (uint64_t blk = b0; blk < b0 + nb; blk += (1ull << BWB_SB_SHIFT) - (blk & ((1ull << BWB_SB_SHIFT) - 1))) {
+			if (blk & ((1ull << BWB_SB_SHIFT) - 1)) continue; /* (on to the next superblock start inside this chunk) */
+			const uint64_t sb = blk >> BWB_SB_SHIFT;
+			const uint32_t first = bwt[blk * 16] >> 28;
+			for (int j = 0; j < 16; j++) {
+				sbcount[sb * 16 + j] = O[blk * 16 + j] - ((first == (uint32_t)j && !(j == 0 && blk * 128 == hdr[4])) ? 1 : 0);
+				c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
+			}
+			HIPCHK(hipStreamSynchronize(c->stream)); /* (the kernels queued so far read the table: a superblock is 16 chunks, this is rare) */
+			HIPCHK(hipMemcpy(d_sbc.p, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice));
+		}
 		HIPCHK(hipEventSynchronize(ev_k[t].e)); /* the kernel that read this staging set two chunks ago */
 		HIPCHK(hipMemcpyAsync(d_bwt[t].p, bwt + w0, nw * 4, hipMemcpyHostToDevice, c->stream));
 		HIPCHK(hipMemcpyAsync(d_O[t].p, O + b0 * 16, nb * 128, hipMemcpyHostToDevice, c->stream));

@@ -30,6 +30,9 @@ typedef struct {
 	bwtint_t *SA;
 	bwtint_t num_sa;
 	bwtint_t sa0_index;
+	/* load_bwt_start: the arrays are filled by loader threads while the GPUs already take the index in */
+	volatile uint64_t blocks_ready;   /* leading 128-character blocks whose bwt words and O rows are in memory (release/acquire) */
+	void *loader;                     /* opaque: the loader threads (NULL: everything is loaded) */
 } bwt_t;
 
 /* reads_t/read_t (io.h:151-194) in structure-of-arrays form: codes are read->seq (A0 G1 C2 T3 N4) */
@@ -63,6 +66,8 @@ void bwb_die(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)
 /* bwt_io.c */
 void store_bwt(const bwt_t *BWT, const char *bwtFname);                /* bwt.c:66-82 */
 bwt_t *load_bwt(const char *bwtFname, int loadSA);                     /* bwt.c:90-125 */
+bwt_t *load_bwt_start(const char *bwtFname, int loadSA);               /* returns after the header: the arrays fill in the background (blocks_ready) */
+void load_bwt_wait(bwt_t *BWT);                                        /* until the whole file is in memory */
 void free_bwt(bwt_t *BWT);
 
 /* index.c */
@@ -75,6 +80,16 @@ void free_ann(fasta_annotations_t *a);
 /* reads.c */
 reads_t *fastq2reads(const char *readsFname);                          /* io.c:410-515 */
 void free_reads(reads_t *reads);
+/* the same parser as a stream: `align` takes the FASTQ in chunks, chunk k+1 is parsed while chunk k is on the GPUs */
+typedef struct fq_stream fq_stream;
+typedef struct {
+	uint32_t n, stride, max_len;  /* reads in the chunk; bytes per read in seq (the chunk's longest read, at least 1) */
+	uint8_t *seq;                 /* [n][stride] read->seq codes (A0 G1 C2 T3 N4), malloc'ed: the consumer frees it */
+	uint16_t *len;                /* [n], malloc'ed */
+} fq_chunk_t;
+fq_stream *fq_open(const char *readsFname);
+int fq_next_chunk(fq_stream *s, uint32_t max_reads, fq_chunk_t *out); /* 0 at the end of the file */
+void fq_close(fq_stream *s);
 
 /* aln_io.c */
 void alns2alnf_bin(const bwb_aln *alns, uint64_t n, FILE *alnFile);    /* align.c:345-382, one read */
@@ -85,7 +100,7 @@ int aln_path_bytes(const bwb_aln *a, unsigned char *path /* >= 272 bytes */); /*
 /* align_gpu.c */
 void set_default_aln_params(aln_params_t *params);                     /* align.c:22-38 */
 int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_t *params, int n_gpus); /* align.c:40-87 */
-int align_reads_inexact_gpu(bwt_t *BWT, reads_t *reads, void *precalc_sa_intervals, aln_params_t *params, char *alnFname, int n_gpus);
+int align_reads_inexact_gpu_stream(bwt_t *BWT, const char *readsFname, aln_params_t *params, char *alnFname, int n_gpus); /* the GPU's align_reads_inexact_parallel (inexact_match.h:40) over a streamed FASTQ */
 
 /* precalc.c */
 void precalc_sa_intervals(bwt_t *BWT, const aln_params_t *params, const char *preFname); /* align.c:200-224: writes <fasta>.pre */

@@ -100,6 +100,12 @@ void bwb_default_params(bwb_params *p);                       /* align.c:22-38 *
  * on the same device - tests do that - should be given a budget with the environment variable BWB_POOL_GB. */
 int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
                        const uint64_t *O, bwb_hip_ctx **out);
+/* The same while the host arrays are still being filled (`bwbble align` reads the 12 GB .bwt of a GRCh37-scale index with several
+ * threads while the GPUs already take it in): *blocks_ready = number of leading 128-character blocks whose bwt words [16 k, 16 k + 16)
+ * and O rows k are in memory, advanced by the caller's loader with release semantics; the upload of a chunk waits for it.  NULL =
+ * everything is there (= bwb_hip_ctx_create).  Several contexts (one per GPU) may follow the same counter. */
+int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                                const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out);
 void bwb_hip_ctx_destroy(bwb_hip_ctx *ctx);
 
 /* Replaces align_reads_inexact[_parallel] for one batch (inexact_match.c:25-168): calculate_d x2 +
