@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <time.h>
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -156,6 +157,21 @@ struct bwb_hip_ctx {
 
 extern "C" const char *bwb_hip_last_error(void) { return g_err.c_str(); }
 extern "C" int bwb_hip_abi_version(void) { return BWB_HIP_ABI_VERSION; }
+
+/* NUMA node of the device's PCIe root (sysfs), -1 when the machine has one node or it cannot be told: `bwbble align` pins the host
+ * thread that drives a GPU, and with it the pinned staging buffers that thread allocates, to that node */
+extern "C" int bwb_hip_device_numa_node(int device) {
+	char bus[64] = { 0 };
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return -1;
+	for (char *q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+	const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+	FILE *f = fopen(path.c_str(), "r");
+	if (!f) return -1;
+	int node = -1;
+	if (fscanf(f, "%d", &node) != 1) node = -1;
+	fclose(f);
+	return node;
+}
 
 extern "C" int bwb_hip_device_count(void) {
 	int n = 0;

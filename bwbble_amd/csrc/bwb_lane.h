@@ -617,6 +617,9 @@ template <typename P, bool WIDE> struct LHeap {
 	 * excess chain and goes back to the block stack in one push when the read ends, so the pool holds what the reads in
 	 * flight need, not the worst case every lane has ever seen. */
 	__device__ __forceinline__ uint32_t alloc(bool &ovf) {
+#ifdef BWB_PRIV_FIRST
+		if (pused < keep) return pbase + pused++;
+#endif
 		if (fhead != NONE32) { /* (round 2 fetched the link one allocation ahead: a register across the whole loop for a load that happens once in 63 pushes) */
 			const uint32_t c = fhead;
 			fhead = chunk_ptr(c)[0].x;

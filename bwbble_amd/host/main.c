@@ -86,7 +86,23 @@ int main(int argc, char *argv[]) {
 		alns2sam(argv[optind + 1], argv[optind + 2], argv[optind + 3], argv[optind + 4], is_multiref, max_diff, n_gpus);
 	} else if (strcmp(argv[1], "dumpreads") == 0) {
 		/* developer command (CPU only, used by the tests): what fastq2reads made of a FASTQ - per read "name<TAB>codes<TAB>quality" */
-		if (argc < 4) { printf("Usage: bwbble dumpreads <reads_fastq> <out_tsv> \n"); exit(1); }
+		if (argc < 4) { printf("Usage: bwbble dumpreads <reads_fastq> <out_tsv> [chunk_reads] \n"); exit(1); }
+		if (argc >= 5) { /* the streaming reader of `align` (fq_next_chunk), chunk by chunk: "codes" per read */
+			fq_stream *fs = fq_open(argv[2]);
+			FILE *g = fopen(argv[3], "w");
+			if (!g) { perror(argv[3]); return 1; }
+			fq_chunk_t ch;
+			while (fq_next_chunk(fs, (uint32_t)atoi(argv[4]), &ch)) {
+				for (uint32_t r = 0; r < ch.n; r++) {
+					for (uint32_t i = 0; i < ch.stride; i++) if (i < ch.len[r]) fputc('0' + ch.seq[(size_t)r * ch.stride + i], g); else if (ch.seq[(size_t)r * ch.stride + i] != 4) fputc('!', g);
+					fputc('\n', g);
+				}
+				free(ch.seq); free(ch.len);
+			}
+			fclose(g);
+			fq_close(fs);
+			return 0;
+		}
 		reads_t *reads = fastq2reads(argv[2]);
 		FILE *f = fopen(argv[3], "w");
 		if (!f) { perror(argv[3]); return 1; }
@@ -97,6 +113,16 @@ int main(int argc, char *argv[]) {
 		}
 		fclose(f);
 		free_reads(reads);
+	} else if (strcmp(argv[1], "bwtcat") == 0) {
+		/* developer command (CPU only, used by the tests): .bwt -> memory through the threaded loader (load_bwt_start / blocks_ready) -> .bwt */
+		if (argc < 4) { printf("Usage: bwbble bwtcat <in_bwt> <out_bwt> \n"); exit(1); }
+		bwt_t *B = load_bwt_start(argv[2], 1);
+		uint64_t last = 0;
+		while (B->loader && last < B->num_occ) { const uint64_t r = __atomic_load_n(&B->blocks_ready, __ATOMIC_ACQUIRE); if (r < last) { printf("blocks_ready went backwards\n"); return 1; } last = r; if (r >= B->num_occ) break; }
+		load_bwt_wait(B);
+		if (B->blocks_ready != B->num_occ) { printf("blocks_ready %llu != %llu\n", (unsigned long long)B->blocks_ready, (unsigned long long)B->num_occ); return 1; }
+		store_bwt(B, argv[3]);
+		free_bwt(B);
 	} else if (strcmp(argv[1], "alncat") == 0) {
 		/* developer command (CPU only, used by the tests): .aln -> memory (alnsf2alns_bin) -> .aln (alns2alnf_bin) */
 		if (argc < 4) { printf("Usage: bwbble alncat <in_aln> <out_aln> \n"); exit(1); }

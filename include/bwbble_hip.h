@@ -88,6 +88,7 @@ typedef struct bwb_hip_ctx bwb_hip_ctx;
 int bwb_hip_abi_version(void);
 
 int bwb_hip_device_count(void);
+int bwb_hip_device_numa_node(int device);                    /* NUMA node of the device's PCIe root, -1 = unknown / single node */
 const char *bwb_hip_last_error(void);
 void bwb_default_params(bwb_params *p);                       /* align.c:22-38 */
 

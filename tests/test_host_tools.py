@@ -323,6 +323,26 @@ def test_fastq_reader_on_cpu(built, golden, tmp_path, fq):
         assert ["".join(map(str, seqs[i, :lens[i]])) for i in range(len(lens))] == [g[1] for g in got]
 
 
+@pytest.mark.parametrize("fq,chunk", [("ragged.fq", 7), ("wgsim100.fq", 1), ("short.fq", 1000), ("toy.fq", 64)])
+def test_streaming_fastq_reader_equals_the_whole_file_reader(built, golden, tmp_path, fq, chunk):
+    """`align` takes the FASTQ in chunks (host/reads.c: fq_next_chunk, the same record scanner): whatever the chunk size, the reads and
+    their codes are those of fastq2reads, and the padding beyond a read's length is code 4."""
+    whole, parts = tmp_path / "whole.tsv", tmp_path / "parts.txt"
+    run([bw.HOST_BIN, "dumpreads", os.path.join(golden, fq), str(whole)])
+    run([bw.HOST_BIN, "dumpreads", os.path.join(golden, fq), str(parts), str(chunk)])
+    assert [ln.split("\t")[1] for ln in open(whole).read().split("\n")[:-1]] == open(parts).read().split("\n")[:-1]
+
+
+def test_threaded_bwt_loader_reads_the_file_exactly(built, golden, tmp_path, monkeypatch):
+    """host/bwt_io.c: the .bwt file read by several threads in units, blocks_ready monotone up to num_occ, the arrays (incl. the
+    sampled SA) identical to the file's."""
+    out = tmp_path / "copy.bwt"
+    for threads in ("1", "5"):
+        monkeypatch.setenv("BWB_LOAD_THREADS", threads)
+        run([bw.HOST_BIN, "bwtcat", os.path.join(golden, "toy.fa.bwt"), str(out)])
+        assert open(out, "rb").read() == open(os.path.join(golden, "toy.fa.bwt"), "rb").read()
+
+
 @pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln"])
 def test_aln_reader_and_writer_round_trip(built, golden, tmp_path, aln):
     """host/aln_io.c without a GPU.  The reference's loader fills aln_path in pair order (align.c:466-476), i.e. it holds the
