@@ -310,6 +310,8 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 template <typename P> struct ListW {
 	int T;        /* intervals so far, including the open tail */
 	P tL, tU;
+	P fL, fU;     /* the list's FIRST interval, once it is final (T >= 2): the step that reads this list next starts with it, and gets it from
+	                 here instead of loading what this step has just stored (kl_search) */
 };
 /* the list being built is the one the current step does not read: buffer base + sel * cap (no pointer kept in registers) */
 template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, int sel, P L, P U, int cap, bool &ovf) {
@@ -318,6 +320,7 @@ template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv
 		if (l.T - 1 >= cap) { ovf = true; return; }
 		Intv<P> *buf = base + sel * cap;
 		buf[l.T - 1].L = l.tL; buf[l.T - 1].U = l.tU;
+		if (l.T == 1) { l.fL = l.tL; l.fU = l.tU; }
 	}
 	l.tL = L; l.tU = U; l.T++;
 }
@@ -506,6 +509,11 @@ __device__ __forceinline__ void prefetch128(u32x4 &dst, const void *p, unsigned 
 	unsigned long long sv;
 	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
 }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void prefetch64(u32x2 &dst, const void *p, unsigned long long mask) {
+	unsigned long long sv;
+	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx2 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
+}
 __device__ __forceinline__ void prefetch32(uint32_t &dst, const void *p, unsigned long long mask) {
 	unsigned long long sv;
 	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dword %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
@@ -532,12 +540,16 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t *bstate;      /* this lane's row: bstate[s] */
 	uint32_t nslots;
 	uint32_t fhead;        /* chunks emptied by pops during this read (LIFO through header .x) */
-	uint32_t pbase, pused, keep; /* the lane's private run of `keep` consecutive chunks and how many of them this read has taken */
+	uint32_t fl_c;         /* the chunk an allocation of THIS iteration took from that list (NONE32: none): its header holds the new head, which
+	                          refill() fetches in place at the end of the iteration - it lands under the next iteration's gather wait */
+	uint32_t pblk, pused, keep;  /* the lane's private run of `keep` consecutive chunks starts at chunk (pblk + threadIdx.x) * keep (pblk: wave-uniform); how
+	                                many of them this read has taken */
 	uint32_t pshared;            /* first chunk of the region's shared part (after every lane's private run) */
-	uint32_t xhead, xtail;       /* chunks the current read took beyond the private chain */
+	uint32_t xhead;              /* chunks the current read took beyond the private chain: the chain's head (the chunk taken last).  Its tail
+	                                (the first one: a constant once set) and the chain's length live in memory - words 0 and 1 of the lane's
+	                                `xs` area, which the callers name with a callable evaluated only on these rare paths: registers */
 	Lds<unsigned long long> blockfree; /* head of this block's stack of recycled chunks (LDS): version<<32 | chunk */
 	Lds<unsigned int> nfree;     /* chunks on that stack */
-	uint32_t xcnt;               /* chunks on the excess chain */
 	uint64_t neW;          /* non-empty buckets, as a window above the cached one: bit k = bucket cb + k.  Entries are popped in
 	                          non-decreasing score order and a child's score exceeds its parent's by at most one penalty, so every
 	                          non-empty bucket lies in [cb, cb + 63] (penalties above 63 are refused, bwb_hip.hip check_params) */
@@ -576,7 +588,7 @@ template <typename P, bool WIDE> struct LHeap {
 		return w;
 	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { fhead = NONE32; pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; sec_valid = false; cprev = 0; stX = stGo = stGe = NONE32; }
+	__device__ __forceinline__ void reset() { /* (fhead is NONE32 already: set when the previous read finished - not here, where a refill may still be in flight) */ pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; sec_valid = false; cprev = 0; stX = stGo = stGe = NONE32; }
 	/* which register holds the state of the side bucket at distance `pen` (a wave-uniform penalty) from cb: 0 = cb itself (zero penalty),
 	 * 1 = stX, 2 = stGo, 3 = stGe.  Equal penalties share the first register of the order X, Go, Ge. */
 	__device__ __forceinline__ int side_of(int pen) const { return pen == 0 ? 0 : (pen == pX ? 1 : (pen == pGo ? 2 : 3)); }
@@ -616,16 +628,14 @@ template <typename P, bool WIDE> struct LHeap {
 	 * came back); the shared part of the region (atomic bump).  What a read takes beyond its private run is threaded on its
 	 * excess chain and goes back to the block stack in one push when the read ends, so the pool holds what the reads in
 	 * flight need, not the worst case every lane has ever seen. */
-	__device__ __forceinline__ uint32_t alloc(bool &ovf) {
-#ifdef BWB_PRIV_FIRST
-		if (pused < keep) return pbase + pused++;
-#endif
-		if (fhead != NONE32) { /* (round 2 fetched the link one allocation ahead: a register across the whole loop for a load that happens once in 63 pushes) */
-			const uint32_t c = fhead;
-			fhead = chunk_ptr(c)[0].x;
-			return c;
-		}
-		if (pused < keep) return pbase + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
+	template <bool FRESH = false, typename XS> __device__ __forceinline__ uint32_t alloc(bool &ovf, XS xs) {
+		/* The list of emptied chunks: its head is in a register, the rest is linked through the chunks' headers.  Taking the head
+		 * leaves the list EMPTY for the rest of the iteration; the new head (a load from the taken chunk's header) is fetched by
+		 * refill() where the lanes have met again, in place, and lands under the next iteration's gather wait: round 3 loaded it here,
+		 * inside this divergent branch, and the wave sat out that round trip in almost every iteration (some lane allocates).
+		 * FRESH: the first allocation of a read (loop top): the list is empty by construction and the register may be in flight. */
+		if (!FRESH && fhead != NONE32) { const uint32_t c = fhead; fl_c = c; fhead = NONE32; return c; }
+		if (pused < keep) return (pblk + threadIdx.x) * keep + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
 		uint32_t c = NONE32;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		while ((uint32_t)old != NONE32) {
@@ -639,13 +649,18 @@ template <typename P, bool WIDE> struct LHeap {
 			if (c >= pool_cap) { ovf = true; return 0; }
 		}
 		__hip_atomic_store(&chunk_ptr(c)[0].z, xhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (xhead == NONE32) xtail = c;
-		xhead = c; xcnt++;
+		uint32_t *x = xs();
+		if (xhead == NONE32) x[0] = c; /* the chain's tail */
+		atomicAdd(x + 1, 1u);          /* its length (no return value: nothing waits for it) */
+		xhead = c;
 		return c;
 	}
 	/* end of a read: hand the chunks it took beyond the private chain to the block */
-	__device__ __forceinline__ void release_excess() {
-		if (xhead == NONE32) return;
+	template <typename XS> __device__ __forceinline__ uint32_t release_excess(XS xs) { /* returns how many chunks the chain held */
+		if (xhead == NONE32) return 0u;
+		uint32_t *x = xs();
+		const uint32_t xtail = x[0], xcnt = x[1];
+		x[1] = 0u;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		for (;;) {
 			__hip_atomic_store(&chunk_ptr(xtail)[0].z, (uint32_t)old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -654,12 +669,13 @@ template <typename P, bool WIDE> struct LHeap {
 			if (__hip_atomic_compare_exchange_strong(blockfree, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
 		}
 		__hip_atomic_fetch_add(nfree, xcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		xhead = xtail = NONE32; xcnt = 0;
+		xhead = NONE32;
+		return xcnt;
 	}
 	/* makes room for k (<= 63) more entries on a bucket whose state is st; returns the state to push from */
-	__device__ __forceinline__ uint32_t reserve(uint32_t st, int k, bool &ovf) {
+	template <bool FRESH = false, typename XS> __device__ __forceinline__ uint32_t reserve(uint32_t st, int k, bool &ovf, XS xs) {
 		if (k > 0 && (st == NONE32 || (int)(st & 63u) + k > CHUNK_SLOTS - 1)) {
-			const uint32_t c = alloc(ovf);
+			const uint32_t c = alloc<FRESH>(ovf, xs);
 			if (ovf) return st;
 			chunk_ptr(c)[0].y = st;
 			return c << 6;
@@ -704,7 +720,7 @@ template <typename P, bool WIDE> struct LHeap {
 	/* Pops the top entry of the cached bucket cb (the best non-empty one).  n_ld += 1 when an entry is fetched from memory.  What the pop
 	 * uncovers comes from the second mirror register, else from memory: pf_top = its state word, pf_hdr = the chunk whose header word is
 	 * wanted for cprev (NONE32: nothing to fetch) - the caller issues both with prefetch() where the lanes of the wave have met again. */
-	__device__ __forceinline__ void pop(LEntry<P> &e, uint32_t &n_ld, uint32_t &pf_top, uint32_t &pf_hdr) {
+	__device__ __forceinline__ void pop(LEntry<P> &e, uint32_t &n_ld, uint32_t &pf_top, uint32_t &pf_hdr, uint32_t &pf_free) {
 		if (!top_valid) { /* (only after the cached bucket changed, or when something else than a match was pushed on top of it) */
 			load_top(cst); n_ld++;
 			/* this rare load is waited for HERE, inside its branch: a wait after the branches have met again would be executed in every
@@ -719,7 +735,7 @@ template <typename P, bool WIDE> struct LHeap {
 			G1 hd = (G1)(uintptr_t)chunk_ptr(cst >> 6);
 			uint32_t pv = cprev;
 			if (pv == 0u) { pv = hd[1]; asm volatile("" :: "v"(pv)); } /* (not known: only the first crossing after the cached bucket changed; waited for inside the branch) */
-			hd[0] = fhead; fhead = cst >> 6;
+			pf_free = cst >> 6; /* (goes onto the lane's list of emptied chunks after the gather's wait - give_back() -: the list's head may be in flight) */
 			cst = pv;
 			if (pv == NONE32) unmark(cb);
 			cprev = 0u;
@@ -729,6 +745,17 @@ template <typename P, bool WIDE> struct LHeap {
 		else if (cst != NONE32) { pf_top = cst; top_valid = true; n_ld++; }
 		else top_valid = false;
 		num_entries--;
+	}
+	/* the chunk a pop emptied goes onto the lane's list (after the gather's wait: the head register is valid again) */
+	__device__ __forceinline__ void give_back(uint32_t c) {
+		if (c != NONE32) { ((__attribute__((address_space(1))) uint32_t *)(uintptr_t)chunk_ptr(c))[0] = fhead; fhead = c; }
+	}
+	/* the new head of the list of emptied chunks, when an allocation of this iteration took the old one (every lane of the wave calls
+	 * this, in uniform control flow; see prefetch128 for the rule) */
+	__device__ __forceinline__ void refill() {
+		const unsigned long long m = __ballot(fl_c != NONE32);
+		if (m) prefetch32(fhead, (const uint32_t *)chunk_ptr(fl_c), m);
+		fl_c = NONE32;
 	}
 	/* issues what pop() asked for (every lane of the wave calls this, in uniform control flow) */
 	__device__ __forceinline__ void prefetch(uint32_t pf_top, uint32_t pf_hdr) {
@@ -832,6 +859,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
 #define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
 #define mysave (R_sc(save) + (size_t)slotv * SAVE_U4)
+	auto xs = [&]() -> uint32_t * { return (uint32_t *)(mysave + 15); }; /* the tail and the length of the lane's excess chain (LHeap::alloc) */
 	const int lcap = (int)sc.lcap;
 	const int nb = kp.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
@@ -839,11 +867,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 	LHeap<P, WIDE> h;
 	const uint32_t region = blockIdx.x % sc.n_regions;
-	h.pbase = ((blockIdx.x / sc.n_regions) * LANE_BLOCK + threadIdx.x) * sc.keep;
+	h.pblk = (blockIdx.x / sc.n_regions) * LANE_BLOCK;
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slotv * sc.brow; h.nslots = sc.nslots;
-	h.xhead = h.xtail = NONE32; h.xcnt = 0; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
+	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.pX = kp.mm_score; h.pGo = kp.gapo_score; h.pGe = kp.gape_score; h.nbk = nb;
+	h.fhead = NONE32; h.fl_c = NONE32;
 	h.reset();
 
 	bool active = false, done = false;
@@ -867,7 +896,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	bool seeding = false;                                   /* -P: the exact steps under way build the read's first heap entries */
 	uint32_t nxw = 0;                                       /* exact tail: summed width of the intervals added to the next list so far (wrapping, like the
 	                                                           reference's int num_best sum :350-352) */
-	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
+	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
 	/* the tail (last interval) of the current list of an exact tail lives in the registers of the popped entry's interval: the tail starts as
 	 * that interval (:345-347), and the entry's interval is not looked at again once its exact tail has begun (registers decide whether three
@@ -877,7 +906,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	h.tw = h.tw1 = h.sw = u32x4{ 0u, 0u, 0u, 0u };
 #define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
 	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
-	uint32_t rec_x = 0, rec_y = 0; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
+	u32x2 rec = { 0u, 0u }; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
 	uint32_t n_bkt = 0, n_est = 0, n_eld = 0, n_rec = 0; /* wave-uniform: buckets fetched, heap entries stored / loaded, per-position records loaded */
@@ -903,9 +932,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		nx.T = (int)a2.x; nxw = a2.y; h.cprev = a2.z; h.fhead = a2.w;
 		e.L = p64(a3.x, a3.y); e.U = p64(a3.z, a3.w); /* (= the tail of the current list in an exact tail) */
 		nx.tL = p64(a4.x, a4.y); nx.tU = p64(a4.z, a4.w);
+		{ const uint4 a14 = mysave[14]; nx.fL = p64(a14.x, a14.y); nx.fU = p64(a14.z, a14.w); }
 		nxi.L = p64(a5.x, a5.y); nxi.U = p64(a5.z, a5.w);
 		e.f = a6.x; e.sa = a6.y; e.runsLo = a6.z; e.runsHi = a6.w;
-		h.pused = a7.x; h.xhead = a7.y; h.xtail = a7.z; h.xcnt = a7.w;
+		h.pused = a7.x; h.xhead = a7.y;
 		h.neW = ((uint64_t)a8.y << 32) | a8.x; h.cb = (int)a8.z; h.cst = a8.w;
 		h.side_load(); /* (the side buckets' states went to memory when the read was parked) */
 		h.num_entries = (int)a9.x; r_vis_s = a9.y; r_vis_a = a9.z; r_pop = a9.w;
@@ -982,7 +1012,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				}
 				if (!skip && !seeding) {
 					/* heap_push(root) inexact_match.c:281 */
-					h.cst = h.reserve(NONE32, 1, ovf0);
+					h.cst = h.template reserve<true>(NONE32, 1, ovf0, xs);
 					if (!ovf0) { h.cst++; h.set_top((P)0, last_row, (uint32_t)rd_len, 0u, ~0u, ~0u); h.store_packed(h.cst, h.tw, h.tw1); h.cprev = NONE32; h.mark(0); h.num_entries = 1; }
 					r_push++;
 				}
@@ -990,7 +1020,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				SET_MAX_DIFF(kp.max_diff); num_best = 0;
 				if (ovf0 || dfail) {
 					if (ovf0) b.status[rid] = ST_SCRATCH_OVF;
-					R_descs[R_wk(slot)].out.n[rid] = 0; h.release_excess(); active = false;
+					R_descs[R_wk(slot)].out.n[rid] = 0; (void)h.release_excess(xs); active = false;
 					__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					publish_done(R_descs[R_wk(slot)].done);
 				}
@@ -999,6 +1029,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (wk.slice_iters && w_iter >= wk.slice_iters) park = true;
 		if (__any(park)) {
 			/* ---- end of the slice for this wave: park the reads under way (word 0 of the save area tells the next launch) ---- */
+			__builtin_amdgcn_s_waitcnt(0x0F70); /* (a refill of the free list's head may be in flight: it is saved below) */
 			if (active) {
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* (lanes of other waves may be waiting for admission) */
 				auto lo = [](P v) { return (uint32_t)v; };
@@ -1011,9 +1042,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				mysave[2] = make_uint4((uint32_t)nx.T, nxw, h.cprev, h.fhead);
 				mysave[3] = make_uint4(lo(e.L), hi(e.L), lo(e.U), hi(e.U));
 				mysave[4] = make_uint4(lo(nx.tL), hi(nx.tL), lo(nx.tU), hi(nx.tU));
+				mysave[14] = make_uint4(lo(nx.fL), hi(nx.fL), lo(nx.fU), hi(nx.fU));
 				mysave[5] = make_uint4(lo(nxi.L), hi(nxi.L), lo(nxi.U), hi(nxi.U));
 				mysave[6] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-				mysave[7] = make_uint4(h.pused, h.xhead, h.xtail, h.xcnt);
+				mysave[7] = make_uint4(h.pused, h.xhead, 0u, 0u);
 				mysave[8] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), (uint32_t)h.cb, h.cst);
 				mysave[9] = make_uint4((uint32_t)h.num_entries, r_vis_s, r_vis_a, r_pop);
 				mysave[10] = make_uint4(r_push, 0u, 0u, 0u);
@@ -1028,7 +1060,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
 		uint32_t ld_cnt = 0; /* heap entries this lane fetches from memory in this iteration */
-		uint32_t pf_top = NONE32, pf_hdr = NONE32; /* what LHeap::pop wants fetched ahead of the gather */
+		uint32_t pf_top = NONE32, pf_hdr = NONE32, pf_free = NONE32; /* what LHeap::pop wants fetched ahead of the gather; the chunk it emptied */
 		P iL = 0, iU = 0;
 		int widx = 0;
 		n_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_iter + (uint32_t)__popcll(__ballot(active)))); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
@@ -1064,7 +1096,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #ifdef BWB_HIST
 				h_mirror = h.top_valid;
 #endif
-				h.pop(e, ld_cnt, pf_top, pf_hdr); /* heap_pop :594-610: the top of the best bucket from its register mirror; what it uncovers is fetched now, under the gather */
+				h.pop(e, ld_cnt, pf_top, pf_hdr, pf_free); /* heap_pop :594-610: the top of the best bucket from its register mirror; what it uncovers is fetched now, under the gather */
 				is_group = (e.sa & 3u) == (uint32_t)STATE_GROUP;
 				/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the
 				 * group's last child, which happens in the next iteration, once the children are in place */
@@ -1122,20 +1154,21 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const int nreq = __popcll(rmask);
 		const bool want_rec = need_rank || (from_pop && rd_len < kp.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
 		n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(want_rec && !(exact_mode && rec_ok)))));
-		typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-		u32x2_t rec_new = { 0u, 0u };
-		bool rec_fresh = false;
+		/* One load: D[i-1], D[i-2] | D_seed pair | seq[len - widx].  It is only ISSUED here, in place (prefetch64: see prefetch128), and
+		 * unpacked after the rank: round 3 unpacked it on the spot - a flat load, which the gather's wait for its exchange array waits for
+		 * as well - so a wave sat out the record's round trip before its gather was even issued, a round trip that the gather's own
+		 * wait covers for free. */
+		bool rec_load = false;
 		if (want_rec) {
 			if (!exact_mode) rec_ok = false; /* (a popped entry has its own position) */
-			if (!rec_ok) { /* (every interval of a multi-interval exact step reads the same record: one step in four at GRCh37 scale) */
-				/* One load: D[i-1], D[i-2] | D_seed pair | seq[len - widx].  It is only ISSUED here - as a global load: a flat load counts as an
-				 * LDS operation too, and the gather's wait for its exchange array would wait for it - and unpacked after the rank: round 3
-				 * unpacked it on the spot, so a wave sat out the record's round trip before its gather was even issued, a round trip that the
-				 * gather's own wait covers for free. */
-				rec_new = *(const __attribute__((address_space(1))) u32x2_t *)(uintptr_t)(recs + widx);
-				rec_fresh = true; /* (merged into rec_x / rec_y after the rank: a copy of the loaded value here would bring the wait back) */
-			}
-			rec_ok = exact_mode; /* (cleared again when the step's last interval is done) */
+			rec_load = !rec_ok;              /* (every interval of a multi-interval exact step reads the same record: one step in four at GRCh37 scale) */
+			rec_ok = exact_mode;             /* (cleared again when the step's last interval is done) */
+		}
+		{
+			const unsigned long long mr = __ballot(rec_load);
+			if (mr) prefetch64(rec, recs + widx, mr);
+		}
+		if (want_rec) {
 			const P pl = (P)(iL - 1);
 			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
 		}
@@ -1144,11 +1177,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		KidCtx<P> kc;
 		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
-		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32 in LHeap::pop) has landed, also when no lane needed a rank */
-		if (rec_fresh) { rec_x = rec_new.x; rec_y = rec_new.y; }
+		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: LHeap::prefetch, ::refill) has landed, also when no lane needed a rank */
+		h.give_back(pf_free);
 		if (want_rec) {
-			wd = rec_x & 0xFFFFu; ws = rec_x >> 16;
-			const int cf = (int)(rec_y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
+			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
+			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
 		}
 		STAMP(14);
@@ -1171,7 +1204,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			/* ---- a deletion group has reached the top of its bucket: its children take its place ---- */
 			const int n = __popc(ne);
 			const uint32_t cst_old = h.cst;
-			const uint32_t st0 = h.reserve(cst_old, n, ovf);
+			const uint32_t st0 = h.reserve(cst_old, n, ovf, xs);
 			if (!ovf && n > 0) {
 				if (st0 != cst_old) h.cprev = cst_old; /* (a new chunk was started: its header names the state before it) */
 				const uint32_t sd = (e.sa & ~3u) | (uint32_t)STATE_D;
@@ -1265,10 +1298,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const int k2 = tG == 2 ? nG : 0;
 					STAMP(9);
 					const uint32_t cst_old = h.cst;
-					uint32_t st0 = h.reserve(cst_old, k0, ovf);
+					uint32_t st0 = h.reserve(cst_old, k0, ovf, xs);
 					const uint32_t stX = h.stX, vGo = h.stGo, vGe = h.stGe, stG = wG == 2 ? vGo : vGe;
-					uint32_t st1 = h.reserve(stX, k1, ovf);
-					uint32_t st2 = h.reserve(stG, k2, ovf);
+					uint32_t st1 = h.reserve(stX, k1, ovf, xs);
+					uint32_t st2 = h.reserve(stG, k2, ovf, xs);
 					STAMP(10);
 					if (!ovf) {
 						/* child entry templates */
@@ -1382,16 +1415,17 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				if (!ovf && s >= curT) {
 					swapped = true;
 					cursel = !cursel; curT = nx.T; cL = nx.tL; cU = nx.tU;
+					if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers, not from what this step has just stored) */
 					nx.T = 0; s = 0; rec_ok = false;
 					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < (seeding ? rd_len - PRECALC_LEN : 0)) exact_done = true; }
 				}
 				/* the interval of the next iteration, when it is not the list's tail (which is in registers): within a step it is on its way
-				 * since the start of this iteration; the first interval of a NEW list (written by this very step: it comes back from L2) is
-				 * fetched now */
+				 * since the start of this iteration; the first interval of a NEW list was kept in registers by list_add (round 4's first
+				 * version loaded what this step had just stored: the wait for it, at the start of the next iteration, was 10 % of the loop) */
 				nxi_valid = !ovf && !exact_done && s != curT - 1;
-				if (nxi_valid && swapped) nxi = (lbase + (cursel ? lcap : 0))[s];
+				(void)swapped;
 			}
 			STAMP(6);
 			if (exact_done && !ovf && seeding) {
@@ -1406,7 +1440,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						if (k == curT - 1) { iL2 = cL; iU2 = cU; }
 						else { const Intv<P> v = (lbase + (cursel ? lcap : 0))[k]; iL2 = v.L; iU2 = v.U; }
 						const uint32_t st_old = st;
-						st = h.reserve(st_old, 1, ovf);
+						st = h.reserve(st_old, 1, ovf, xs);
 						if (!ovf) { if (st != st_old) h.cprev = st_old; st++; h.set_top(iL2, iU2, ent_f, ent_sa, ~0u, ~0u); h.store_packed(st, h.tw, h.tw1); }
 					}
 					if (!ovf) { h.cst = st; h.mark(0); h.num_entries = curT; h.sec_valid = false; r_push += (uint32_t)curT; }
@@ -1429,12 +1463,27 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					else {
 						const int alen2 = ((int)((e.sa >> 2) & 255u) + e_i) & 255; /* :365 */
 						const Intv<P> *lst = lbase + (cursel ? lcap : 0);
+						/* the list's first interval (when it has several) is in registers - nxi, from the swap above - and so is its tail: a list
+						 * of two costs no load at all; what lies in between is loaded several intervals at a time (round 3 loaded one per
+						 * trip of a loop: a chain of dependent waits that, with some lane of a wave ending an exact tail in most iterations,
+						 * took 9 % of the loop) */
 						int k = 0;
+						if (curT >= 2) { add_aln(nxi.L, nxi.U, e_score, alen2); k = 1; }
 						if (e_go == 0) { /* no duplicate check (align.c:273-280 applies to gapped entries): four list loads in flight at a time */
 							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)sc.acap; k += 4) {
 								const Intv<P> v0 = lst[k], v1 = lst[k + 1], v2 = lst[k + 2], v3 = lst[k + 3];
 								add_aln(v0.L, v0.U, e_score, alen2); add_aln(v1.L, v1.U, e_score, alen2);
 								add_aln(v2.L, v2.U, e_score, alen2); add_aln(v3.L, v3.U, e_score, alen2);
+							}
+							const int rem = curT - 1 - k; /* 0..3 intervals of the list in memory are left */
+							if (rem > 0 && n_alns + rem <= (int)sc.acap) {
+								Intv<P> v0 = lst[k], v1 = v0, v2 = v0;
+								if (rem > 1) v1 = lst[k + 1];
+								if (rem > 2) v2 = lst[k + 2];
+								add_aln(v0.L, v0.U, e_score, alen2);
+								if (rem > 1) add_aln(v1.L, v1.U, e_score, alen2);
+								if (rem > 2) add_aln(v2.L, v2.U, e_score, alen2);
+								k += rem;
 							}
 						}
 						for (; k < curT && !ovf; k++) {
@@ -1449,6 +1498,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 
 		STAMP(15);
+		h.refill(); /* (the lanes have met again) */
 		HIST(H_TOP_RELOAD, ld_cnt != 0);
 		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
@@ -1458,6 +1508,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);
 		if (finish) {
+			__builtin_amdgcn_s_waitcnt(0x0F70); /* (a refill of the free list's head may be in flight: the register is cleared below) */
+			h.fhead = NONE32;
 			const SlotDesc &d = R_descs[rd_myslot]; /* (the read may belong to an earlier slot than the one this launch feeds from) */
 			const OutBuf out = d.out;
 			unsigned long long off = 0;
@@ -1480,9 +1532,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			}
 			publish_done(d.done);
 			/* leave every bucket state empty for the next read and give its chunks back */
-			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_sum, (h.pused + h.xcnt + 15u) >> 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const uint32_t xchunks = h.release_excess(xs);
+			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_sum, (h.pused + xchunks + 15u) >> 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			h.release_excess();
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			h.bstate[h.cb] = NONE32;
 			while (h.neW) { const int k = h.best(nb); h.bstate[k] = NONE32; h.unmark(k); }
