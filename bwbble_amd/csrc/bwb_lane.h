@@ -139,6 +139,48 @@ __device__ __forceinline__ void pair_setup(P last_row, bool need, P pL, P pU, in
  * the 8 owners of its column with 128-bit reads; round 2 used 16 ds_bpermute).
  * Round `first` == 0 fetches the L rows and the U rows of the compacted owners [0, NU_MAX); a later round (first = NU_MAX, ...)
  * only the U rows of the owners [first, first + NU_MAX).  Called by EVERY lane of the wave. */
+#ifdef BWB_GATHER2
+/* Variant (A/B): the same gather with fewer instructions per load (12 loads per iteration): (1) an owner that wants no bucket (an idle lane, a
+ * compacted U slot beyond the wave's count) loads bucket 0 instead of being masked off - its row is never read (the zero row stands in) - so
+ * no load needs an exec mask, and the U instructions beyond the wave's count are skipped by a scalar branch; (2) the exchange array carries
+ * bucket << 3, the bucket's index in 16-byte slices, so that the address is one add and one shift-add; (3) the LDS destination (M0) is built
+ * from a scalar copy of the wave's LDS base instead of a vector add and a readfirstlane per load. */
+template <typename P>
+__device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, const PairInfo<P> &pi, int first, Lds<u32x4> stage, int lane) {
+	const int sub = lane >> 3, p = lane & 7;
+	Lds<uint32_t> xch = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF);
+	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU_MAX;
+	const uint32_t k = pi.ku - (uint32_t)first;
+	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? 0u : pi.blkL << 3;
+	xch[64 + lane] = 0u;
+	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU << 3;
+	u32x4 a0 = { 0u, 0u, 0u, 0u }, a1 = a0;
+	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
+	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
+	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */
+	uint32_t sv = (uint32_t)(uintptr_t)stage;
+	asm volatile("" : "+v"(sv)); /* (not loop-invariant for the compiler: a scalar kept across the loop would be one more spilled SGPR) */
+	const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
+	const int nUr = pi.nU - first; /* (wave-uniform) U owners of this round: those beyond NU_MAX wait for the next */
+	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+	if (first == 0) {
+#pragma unroll
+		for (int r = 0; r < 8; r++) {
+			const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+			__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
+		}
+	}
+	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
+#pragma unroll
+	for (int r = 0; r < NU_MAX / 8; r++) {
+		const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+		if (8 * r < nUr) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
+#else
 template <typename P>
 __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, const PairInfo<P> &pi, int first, Lds<u32x4> stage, int lane) {
 	const int sub = lane >> 3, p = lane & 7;
@@ -170,6 +212,8 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
+
+#endif
 
 /* Rank from a 64-character bucket (bwb_device.h): acc[j] = #j among the first n (0..32) characters of the sub-block whose planes are p,
  * j = 1..15: ONE masked pass. */
@@ -366,7 +410,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* the interval of the next iteration, when it comes from the list in memory */
 	int c = 4, cnext = 4; /* seq[r] and seq[r - 1]: loaded once per position, one position ahead (round 2 loaded seq[r] in every iteration) */
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
-	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0;
+	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
 	int32_t nm = 0, prev_nm = 0;
 	uint32_t prev_byte = 0, cntN = 0;
 	unsigned long long vis = 0;
@@ -410,8 +454,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			if (c > 3 && phase == 0) cntN++;
 			if (c <= 3) {
 				if (s == curT - 1) { iL = cL; iU = cU; }
-				else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous iteration */
-				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; }
+				else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched ahead of the previous iteration's gather, or the new list's first interval (registers) */
+				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; asm volatile("" :: "v"(iL), "v"(iU)); } /* (never in the steady state: waited for inside the branch) */
+				/* the interval of the position's NEXT iteration, when it is one of the list in memory: fetched now, under this iteration's gather
+				 * (round 3 fetched it at the end of the iteration and used it at the start of the next: an exposed round trip per iteration) */
+				if (s + 1 < curT - 1) nxi = (lbase + cursel * cap)[s + 1];
 			}
 		}
 		const bool need = active && c <= 3;
@@ -439,6 +486,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			/* position finished: swap lists (inexact_match.c:234-237) */
 			cursel ^= 1;
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
+			if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers - list_add -, not from what this step has just stored) */
 			nx.T = 0; s = 0;
 			if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
 				cL = 0; cU = last_row; curT = 1; z++;
@@ -477,9 +525,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				}
 			}
 		}
-		/* the interval of the next iteration, when it is not the list's tail (which is in registers): on its way now */
+		/* the interval of the next iteration, when it is not the list's tail (which is in registers): already in nxi (see above) */
 		nxi_valid = active && c <= 3 && s != curT - 1;
-		if (nxi_valid) nxi = (lbase + cursel * cap)[s];
 	}
 	if (vis) { atomicAdd(&stats[STAT_VIS_SINGLE], vis); atomicAdd(&stats[STAT_VIS_CALCD], vis); }
 	if (lane == 0 && n_bkt) atomicAdd(&stats[STAT_BKT_CALCD], (unsigned long long)n_bkt);
@@ -856,11 +903,19 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	 * decides whether three waves fit a SIMD). */
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	uint32_t slotv = slot;
-#define lbase ((Intv<P> *)sc.lists + (size_t)slotv * 2 * sc.lcap)
-#define myalns (sc.alns + (size_t)slotv * sc.acap * 2)
+	/* The bases and sizes of the lane's scratch areas that the loop uses in (almost) every iteration, made OPAQUE scalar values: with more
+	 * wave-uniform values alive than scalar registers, the compiler drops kernel arguments and loads them again from the kernarg segment
+	 * where they are used - an s_load and a full wait on the scalar cache, five times per iteration in the first round-4 kernel
+	 * (SQ_INSTS_SMEM, profiles/r4_c3_pmc_sq.txt).  A value it cannot see through is kept, or parked in a VGPR lane (one v_readlane). */
+	typedef __attribute__((address_space(1))) unsigned char *GlobalBytes; /* (global pointers: a pointer made from an integer would be a flat one) */
+	GlobalBytes sc_lists = (GlobalBytes)sc.lists, sc_alns = (GlobalBytes)sc.alns, sc_bstate = (GlobalBytes)sc.bstate;
+	uint32_t sc_lcap = sc.lcap, sc_acap = sc.acap, sc_brow = sc.brow;
+	asm volatile("" : "+s"(sc_lists), "+s"(sc_alns), "+s"(sc_bstate), "+s"(sc_lcap), "+s"(sc_acap), "+s"(sc_brow));
+#define lbase ((Intv<P> *)(unsigned char *)sc_lists + (size_t)slotv * 2 * sc_lcap)
+#define myalns ((uint4 *)(unsigned char *)sc_alns + (size_t)slotv * sc_acap * 2)
 #define mysave (R_sc(save) + (size_t)slotv * SAVE_U4)
 	auto xs = [&]() -> uint32_t * { return (uint32_t *)(mysave + 15); }; /* the tail and the length of the lane's excess chain (LHeap::alloc) */
-	const int lcap = (int)sc.lcap;
+	const int lcap = (int)sc_lcap;
 	const int nb = kp.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
 	const P last_row = (P)(ix.length - 1);
@@ -869,7 +924,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	const uint32_t region = blockIdx.x % sc.n_regions;
 	h.pblk = (blockIdx.x / sc.n_regions) * LANE_BLOCK;
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
-	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = sc.bstate + (size_t)slotv * sc.brow; h.nslots = sc.nslots;
+	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow; h.nslots = sc.nslots;
 	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.pX = kp.mm_score; h.pGo = kp.gapo_score; h.pGe = kp.gape_score; h.nbk = nb;
 	h.fhead = NONE32; h.fl_c = NONE32;
@@ -953,7 +1008,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	for (;;) {
 		STAMP(7);
 		asm volatile("" : "+v"(slotv));
-		h.bstate = sc.bstate + (size_t)slotv * sc.brow;
+		h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow;
 		bool admit = !active && !done;
 		if (admit) {
 			/* admission: what a read will need is not known in advance, and a read that finds the pool empty is given up and
@@ -1079,7 +1134,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					if (a.x == (uint32_t)L && a.y == (uint32_t)((uint64_t)L >> 32) && a.z == (uint32_t)U && a.w == (uint32_t)((uint64_t)U >> 32)) return;
 				}
 			}
-			if (n_alns >= (int)sc.acap) { ovf = true; return; }
+			if (n_alns >= (int)sc_acap) { ovf = true; return; }
 			myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
 			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), e.runsLo, e.runsHi); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
 			n_alns++;
@@ -1186,7 +1241,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 		STAMP(14);
 		asm volatile("" : "+v"(slotv));
-		h.bstate = sc.bstate + (size_t)slotv * sc.brow;
+		h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow;
 		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504); their states are in registers (LHeap) */
 		const int e_state = (int)(e.sa & 3u);
 		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
@@ -1470,13 +1525,13 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						int k = 0;
 						if (curT >= 2) { add_aln(nxi.L, nxi.U, e_score, alen2); k = 1; }
 						if (e_go == 0) { /* no duplicate check (align.c:273-280 applies to gapped entries): four list loads in flight at a time */
-							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)sc.acap; k += 4) {
+							for (; k + 4 <= curT - 1 && n_alns + 4 <= (int)sc_acap; k += 4) {
 								const Intv<P> v0 = lst[k], v1 = lst[k + 1], v2 = lst[k + 2], v3 = lst[k + 3];
 								add_aln(v0.L, v0.U, e_score, alen2); add_aln(v1.L, v1.U, e_score, alen2);
 								add_aln(v2.L, v2.U, e_score, alen2); add_aln(v3.L, v3.U, e_score, alen2);
 							}
 							const int rem = curT - 1 - k; /* 0..3 intervals of the list in memory are left */
-							if (rem > 0 && n_alns + rem <= (int)sc.acap) {
+							if (rem > 0 && n_alns + rem <= (int)sc_acap) {
 								Intv<P> v0 = lst[k], v1 = v0, v2 = v0;
 								if (rem > 1) v1 = lst[k + 1];
 								if (rem > 2) v2 = lst[k + 2];
