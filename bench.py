@@ -176,7 +176,9 @@ def main():
     kern_ms = st.ms_calc_d + st.ms_search
     visits = st.visits_single + st.visits_alphabet
     dt, kern_ms, visits_all = grp.reduce_step(dt, kern_ms, float(visits))  # MAX time over ranks, SUM of visits
-    rank_rates = [v[0] for v in grp.all_gather_pairs(int(a.reads * a.steps / dt_rank), 0)]  # every rank's own reads/s (its own clock between the barriers)
+    gathered = grp.all_gather_pairs(int(a.reads * a.steps / dt_rank), int(t_ctx * 1000))
+    rank_rates = [v[0] for v in gathered]  # every rank's own reads/s (its own clock between the barriers)
+    rank_ctx_ms = [v[1] for v in gathered]  # every rank's .bwt -> HBM time (the ranks map one file: its pages are shared)
     off0, alns0 = ctx.slot_result(0)  # hits of batch 0 = the first B reads of this shard
 
     # every rank re-aligns a sample of its right neighbour's shard: the bytes must not depend on which GPU did the work
@@ -253,6 +255,7 @@ def main():
         out["shard_sample_parity"] = shard_check
     if world > 1:
         out["per_rank_reads_per_s"] = {"min": min(rank_rates), "max": max(rank_rates)}
+        out["per_rank_index_to_hbm_s"] = {"min": round(min(rank_ctx_ms) / 1e3, 2), "max": round(max(rank_ctx_ms) / 1e3, 2)}
         n1 = stored_n1_value(a)
         if n1:
             out["efficiency_vs_stored_n1"] = {"value": round(value / world / n1["value"], 4), "n1_reads_per_s": n1["value"], "n1_source": n1["source"],
@@ -263,6 +266,8 @@ def main():
         out["rank_micro"] = rank_micro(ctx, index_mb)
         if a.ndiff != 0:
             out["also"] = {"n0": also_n0(ctx, bw, batch, nb, B)}
+        ctx.flush()
+        out["cli_end_to_end"] = cli_end_to_end(a, fa, fq, flags, value, ctx, bw)  # (last: it closes this process's context)
     print(json.dumps(out))
     grp.close()
 
@@ -280,11 +285,11 @@ def source_hash():
 
 
 def measured_traffic(a, B, dom_name, dom):
-    """HBM traffic of the dominant kernel per launch from the committed rocprofv3 --pmc passes of this workload (profiles/r3_*_pmc.json,
+    """HBM traffic of the dominant kernel per launch from the committed rocprofv3 --pmc passes of this workload (profiles/r<N>_*_pmc.json,
     written by tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, corrected with the calibration measured by
     tools_exp/gather_bench: bucket requests x2, metadata requests x k) - only when the profile was taken on THIS kernel source."""
     import glob
-    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_*_pmc.json")), reverse=True):
+    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc.json")), reverse=True):
         pj = json.load(open(prof))
         if (pj.get("genome_mb"), pj.get("reads"), pj.get("ndiff"), pj.get("read_len", 100)) != (a.genome_mb, B, a.ndiff, a.read_len) or dom_name not in pj:
             continue
@@ -300,7 +305,7 @@ def measured_traffic(a, B, dom_name, dom):
 def stored_n1_value(a):
     """the 1-GPU bench line of the same workload kept under profiles/ (for the informational efficiency figure of a multi-GPU run)"""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_bench_line*.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_bench_line*.json")), reverse=True):
         try:
             j = json.loads(open(f).read().strip().splitlines()[-1])
         except Exception:
@@ -331,6 +336,32 @@ def end_to_end(ctx, p, batch, ns, B, value):
     v = ne * B / dt
     return {"value": round(v, 1), "unit": "reads/s", "batches": ne, "slots": ns, "of_value": round(v / value, 4),
             "includes": "H2D of reads (pinned staging), kl_calc_d + kl_search, D2H of the hit log, reordering into read order"}
+
+
+def cli_end_to_end(a, fa, fq, flags, value, ctx, bw):
+    """What a user of the product sees: the wall time of the C CLI - `bwbble align` from process start to exit - on this rank's whole
+    FASTQ shard (the read pool), .bwt file -> host -> HBM, FASTQ parsing, alignment, .aln writing included.  The CLI overlaps the
+    three (host/align_gpu.c: loader threads, streamed context creation, reader thread, ordered writer).  The Python context keeps
+    its index but gives its heap chunk pool back first (BWB_POOL_GB-sized pools for both would not fit the CLI's own)."""
+    out_aln = fq + ".cli.aln"
+    try:
+        ctx.close()  # the CLI's context sizes its pool from what is free
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    r = subprocess.run([bw.HOST_BIN, "align"] + flags + [fa, fq, out_aln], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    dt = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("GPUs:")]
+    n = a.pool
+    res = {"value": round(n / dt, 1), "unit": "reads/s", "reads": n, "wall_s": round(dt, 2), "of_value": round(n / dt / value, 4),
+           "command": "bwbble align " + " ".join(flags) + " <fasta> <fastq> <out.aln>", "cli_summary": line[-1] if line else ""}
+    try:
+        os.remove(out_aln)
+    except OSError:
+        pass
+    return res
 
 
 def rank_micro(ctx, index_mb):
@@ -416,6 +447,35 @@ def cpu_baseline(a, fa, fq, flags, off, alns, bw):
         sample = final["reads"]
         ref_bytes = open(sfq + ".aln", "rb").read()
         phys = cores // 2 if cores >= 4 else cores  # the GPU boxes expose 2 hardware threads per core
+        # The reference freads the 12 GB index from one thread (bwt.c:90-125): first touch puts it on that thread's NUMA node, and the
+        # other socket's threads walk it over the inter-socket link.  The same binary under `numactl --interleave=all` (when the box
+        # has it) says what the reference does once its pages are spread - reported next to the plain run, not instead of it.
+        import shutil
+        if shutil.which("numactl") and not a.cpu_sample:
+            def t_run_il(path, out, t):
+                t0 = time.perf_counter()
+                subprocess.run(["numactl", "--interleave=all", ref_bin, "align"] + flags + ["-t", str(t), fa, path, out], check=True, stdout=subprocess.DEVNULL)
+                return time.perf_counter() - t0
+            il = []
+            for t in ts:
+                n_il = min(200 * t if t == best_t else 64 * t, a.reads)
+                sfq_il = fq + f".sample{n_il}"
+                if not os.path.exists(sfq_il):
+                    head_fastq(n_il, sfq_il)
+                tl, ta = t_run_il(one, one + ".il.aln", t), t_run_il(sfq_il, sfq_il + ".il.aln", t)
+                sec = max(ta - tl, 1e-3)
+                il.append({"threads": t, "reads": n_il, "wall_s": round(ta, 2), "load_s": round(tl, 2), "reads_per_s": round(n_il / sec, 1),
+                           "reads_per_s_per_thread": round(n_il / sec / t, 2)})
+            bi = max(il, key=lambda r: r["reads_per_s"])
+            res["interleaved"] = {"value": bi["reads_per_s"], "threads": bi["threads"], "reads_per_s_per_thread": bi["reads_per_s_per_thread"],
+                                  "sweep": il, "command": "numactl --interleave=all oracle/_ref/bwbble align ..."}
+        else:
+            res["interleaved"] = None if a.cpu_sample else "numactl not installed on this box"
+        try:
+            nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+        except OSError:
+            nodes = None
+        res["numa_nodes"] = nodes
         res.update({"value": final["reads_per_s"], "kind": "reference", "threads": best_t, "reads_per_s_per_thread": final["reads_per_s_per_thread"],
                     "reads_per_s_per_core": round(final["reads_per_s"] / min(best_t, phys), 2), "sweep": sweep, "final": final,
                     "sample": f"first {sample} reads of the same FASTQ ({final['reads_per_thread']} per thread), oracle/_ref/bwbble align -t {best_t} "

@@ -27,6 +27,15 @@ def test_prefetched_registers_are_not_read_before_the_wait(compiled):
         assert not errs, errs
 
 
+def test_prefetched_registers_in_the_test_build():
+    """the small-superblock test build (make testlib) is a different compilation: the same proof for it"""
+    import check_prefetch_regs as cpr
+    res, _ = cpr.check_all(["-DBWB_SB_SHIFT=13", "-DBWB_TEST_POS_BIAS=0x500000000ull"])
+    assert len(res) == 4
+    for k, (sites, errs) in res.items():
+        assert sites >= 2 and not errs, (k, errs)
+
+
 def test_search_kernel_register_budget(compiled):
     _, remarks = compiled
     ks = {k: v for k, v in remarks.items() if "kl_search" in k}
