@@ -32,6 +32,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 ALG_BYTES_PER_VISIT = 192  # one reference checkpoint row (128 B) + one packed BWT block (64 B)
+REC_BYTES = 16  # what kl_calc_d hands to kl_search: one 16-byte record per four read positions (bwb_kernels.h: rec_put)
+
+
+def rec_bytes_written(read_len):
+    """bytes of records kl_calc_d writes per read: the zero-initialised records, then their bytes (each once, some twice)"""
+    return 2 * REC_BYTES * ((read_len >> 2) + 1)
 DEV_BYTES_PER_BUCKET = 128  # what the device layout fetches per rank visit (bwb_device.h)
 
 
@@ -215,9 +221,9 @@ def main():
                 "device_bytes_per_step": int(dev / a.steps), "device_bytes_per_launch": int(dev / max(launches, 1)),
                 "device_GBs": round(dev / sec / 1e9, 1) if ms else 0.0, "device_frac": round(dev / sec / 1e9 / HBM_PEAK_GBS, 4) if ms else 0.0,
                 "Gvisits_per_s": round(vis / sec / 1e9, 2) if ms else 0.0, "ref_layout_GBs": round(vis * ALG_BYTES_PER_VISIT / sec / 1e9, 1) if ms else 0.0}
-    heap_bytes = (st.heap_entries_stored + st.heap_entries_loaded) * esz + st.record_loads * 8
+    heap_bytes = (st.heap_entries_stored + st.heap_entries_loaded) * esz + st.record_loads * REC_BYTES
     k_search = kernel(vis_search, st.ms_search, st.launches_search, st.bucket_loads_search, heap_bytes)
-    k_calcd = kernel(vis_calcd, st.ms_calc_d, st.launches_calc_d, st.bucket_loads_calc_d, B * a.steps * 8 * (a.read_len + 2))
+    k_calcd = kernel(vis_calcd, st.ms_calc_d, st.launches_calc_d, st.bucket_loads_calc_d, B * a.steps * rec_bytes_written(a.read_len))
     dom_name, dom = ("kl_search", k_search) if st.ms_search >= st.ms_calc_d else ("kl_calc_d", k_calcd)
     traffic, traffic_src = measured_traffic(a, B, dom_name, dom)
     index_mb = 2 * bwt.length / 1e6  # one 128-byte bucket per 64 BWT characters
@@ -396,7 +402,7 @@ def also_n0(ctx, bw, batch, nb, B):
     d0 = time.perf_counter() - t0
     s0 = ctx.stats()
     ach0 = s0.visits_calc_d * ALG_BYTES_PER_VISIT / (s0.ms_calc_d * 1e-3) / 1e9
-    dev0 = (s0.bucket_loads_calc_d * DEV_BYTES_PER_BUCKET + k * B * 8 * 102) / (s0.ms_calc_d * 1e-3) / 1e9
+    dev0 = (s0.bucket_loads_calc_d * DEV_BYTES_PER_BUCKET + k * B * rec_bytes_written(100)) / (s0.ms_calc_d * 1e-3) / 1e9
     return {"workload": f"{k} of the same batches, align -n 0 (CLI default)", "value": round(k * B / d0, 1), "unit": "reads/s",
             "ms_per_step": round(d0 / k * 1e3, 3), "dominant_kernel": "kl_calc_d", "kernel_ms_per_launch": round(s0.ms_calc_d / max(s0.launches_calc_d, 1), 3),
             "device_GBs": round(dev0, 1), "device_frac": round(dev0 / HBM_PEAK_GBS, 4), "ref_layout_GBs": round(ach0, 1),

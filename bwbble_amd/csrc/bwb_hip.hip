@@ -518,8 +518,7 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	s.n_tot = n_reads + (use_ghost && s.inherit ? 1u : 0u);
 	if (n_bad) fprintf(stderr, "[bwbble_hip] warning: %u read(s) longer than 255 bases%s get an empty alignment record\n", n_bad, p->use_precalc ? " or shorter than 12 (-P)" : "");
 	s.n_reads = n_reads; s.stride = std::min<uint32_t>(stride, std::max<uint32_t>(maxlen, 1)); s.maxlen = maxlen;
-	/* per read: an 8-byte record {D pair, D_seed pair, base} for i = 0..maxlen+1, then 16 bytes (work, N count) */
-	s.dstride = 8 * (maxlen + 2) + 16;
+	s.dstride = REC_BYTES * rec_count(maxlen) + 16; /* per read: its records (bwb_kernels.h: rec_put), then 16 bytes (work, N count) */
 	const size_t nr = s.n_tot ? s.n_tot : 1;
 	HIPCHK(s.d_reads.reserve(nr * s.stride));
 	HIPCHK(s.d_lens.reserve(nr * 2));

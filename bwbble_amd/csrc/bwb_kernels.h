@@ -34,7 +34,7 @@ struct Batch {
 	const uint8_t *reads;     /* [n][stride] read->seq codes */
 	const uint16_t *lens;
 	uint32_t n_reads, stride;
-	uint8_t *dbuf;            /* [n][dstride]: one 8-byte record per read position i: u16 {D[i-1],D[i-2]}, u16 {Dseed[si-1],Dseed[si-2]}, u8 seq[len-i];
+	uint8_t *dbuf;            /* [n][dstride]: what kl_calc_d hands to kl_search, one 16-byte RECORD PER FOUR READ POSITIONS (rec_put / rec_get below),
 	                             then the read's N count (dstride-4) and its calculate_d work (dstride-8) */
 	uint32_t dstride;
 	uint8_t *status;          /* per read */
@@ -75,6 +75,27 @@ enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, S
        STAT_WAVE_ITERS = 16, STAT_STAMPS = 24, STAT_HIST = 40 /* BWB_HIST diagnostic build */, STAT_WORDS = 104 };
 
 template <typename P> struct Intv { P L, U; };
+
+/* The per-position data of a read, as kl_calc_d leaves it for kl_search.  An entry at read position i (aln_entry_t.i) consults
+ * D[i-1], D[i-2] (inexact_match.c:317,399-405), D_seed[si-1], D_seed[si-2] with si = i - (len - seed_length) (:321-328,408-415) and the
+ * base seq[len - i] it extends with.  One byte per D value: min(num_diff, 127) | 0x80 when sa_intv_width equals the previous
+ * position's (the only way the width is ever used, :402-403,411-412).  Record m (16 bytes) serves the FOUR positions i = 4m .. 4m+3:
+ *   bytes 0..5    D[k]   for k = 4m-2 .. 4m+3        (k < 0: 0)
+ *   bytes 6..7    the bases of i = 4m .. 4m+3, 4 bits each (i & 3 = nibble)
+ *   bytes 8..13   DS[k]  for the same k, DS[k] = D_seed[k - (len - seed_length)] - the seed's bounds moved to the read's positions
+ *   bytes 14..15  m (the record's tag: kl_search keeps the record in registers and checks it against i >> 2)
+ * so consecutive records overlap by two D bytes, and a search that walks down a read - a popped entry's match child is at i - 1 and is
+ * popped next in 55 % of the pops - loads a record once per four positions (round 3: an 8-byte record per position, 0.8 loads per loop
+ * iteration, 70 % of the kernel's metadata read requests). */
+#define REC_BYTES 16
+__host__ __device__ __forceinline__ uint32_t rec_count(uint32_t len) { return (len >> 2) + 1u; }
+/* the byte D[k] (arr = 0) or DS[k] (arr = 8), k >= -2: in record (k + 2) >> 2, and again in the record before it when it is one of a record's first two */
+__device__ __forceinline__ void rec_put(uint8_t *recs, int arr, int k, uint32_t v) {
+	const int m = (k + 2) >> 2, t = (k + 2) & 3;
+	recs[REC_BYTES * m + arr + t] = (uint8_t)v;
+	if (t < 2 && m > 0) recs[REC_BYTES * (m - 1) + arr + 4 + t] = (uint8_t)v;
+}
+__device__ __forceinline__ uint32_t rec_get(const uint8_t *recs, int arr, int k) { return recs[REC_BYTES * ((k + 2) >> 2) + arr + ((k + 2) & 3)]; }
 
 /* io.h:29,109: read base c (A0 G1 C2 T3) is compatible with code j iff gray(c) & grayVal[j]; N(10) excluded
  * (nucl_bases_table io.h:102-106).  Bit j of the mask = code j is a member. */
@@ -223,8 +244,8 @@ __global__ void k_gather(const uint4 *log, const uint64_t *off, const uint32_t *
 /* D_seed of a read that is not longer than the seed.  The reference computes D_seed only when len > seed_length
  * (inexact_match.c:62-64) but inexact_match reads it regardless (:321-328,408-415): the serial path (-t 1, one buffer for the
  * whole file, :35) therefore sees the bounds of the LAST LONGER READ BEFORE IT in the file - zeros when there is none.
- * src[r] names that read (host: slot_upload); the per-position records carry {Dseed[si-1], Dseed[si-2]} with
- * si = i - (len - seed_length), so read r takes the pair of position i + len_q - len_r of read q.  Runs after kl_calc_d. */
+ * src[r] names that read (host: slot_upload); the records carry the seed's bounds at the read's own positions (rec_put), so read r
+ * takes the byte of position k + len_q - len_r of read q.  Runs after kl_calc_d. */
 __global__ void k_dseed_inherit(Batch b, const uint32_t *src, uint32_t n) {
 	const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= n) return;
@@ -234,7 +255,8 @@ __global__ void k_dseed_inherit(Batch b, const uint32_t *src, uint32_t n) {
 	const int lr = b.lens[r], lq = b.lens[q];
 	uint8_t *rr = b.dbuf + (size_t)r * b.dstride;
 	const uint8_t *rq = b.dbuf + (size_t)q * b.dstride;
-	for (int i = 0; i <= lr; i++) /* (i = 0: the hit check of a read shorter than the seed) */ *(uint16_t *)(rr + 8 * i + 2) = *(const uint16_t *)(rq + 8 * (i + lq - lr) + 2);
+	/* DS of read r at position k (of r) = DS of read q at position k + len_q - len_r (of q): the same seed index */
+	for (int k = -2; k < lr; k++) rec_put(rr, 8, k, rec_get(rq, 8, k + lq - lr));
 }
 
 /* SA[row] by the invPsi walk (bwt.c:311-329): one octet per row */

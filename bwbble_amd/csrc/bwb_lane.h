@@ -412,7 +412,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
 	int32_t nm = 0, prev_nm = 0;
-	uint32_t prev_byte = 0, cntN = 0;
+	uint32_t bacc = 0, cntN = 0; /* (bacc: the bases of the record being filled) */
 	unsigned long long vis = 0;
 	uint32_t r_vis = 0, n_bkt = 0;
 	const uint8_t *seq = b.reads;
@@ -427,7 +427,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 				if (unrep) len = 0;
 				r_vis = 0;
 				seq = b.reads + (size_t)rid * b.stride;
-				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; prev_byte = 0; cntN = 0;
+				phase = 0; plen = len; r = len - 1; z = 0; s = 0; cursel = 0; nm = 0; prev_nm = 0; bacc = 0; cntN = 0;
+				{ /* the read's records (bwb_kernels.h: rec_put) start as zeros with their tags: D[-2], D[-1], the seed's DS below its first position */
+					uint4 *rz = (uint4 *)(b.dbuf + (size_t)rid * b.dstride);
+					for (uint32_t m = 0; m < rec_count((uint32_t)len); m++) rz[m] = make_uint4(0u, 0u, 0u, m << 16);
+				}
 				c = len > 0 ? seq[len - 1] : 4; cnext = len > 1 ? seq[len - 2] : 4;
 				cL = 0; cU = last_row; curT = 1; nxi_valid = false;
 				nx.T = 0;
@@ -438,10 +442,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 					 * inexact_match.c:35) - k_dseed_inherit copies those in afterwards - or the calloc'd zeros written here (num_diff 0,
 					 * equal widths) when there is no such read. */
 					uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
-					for (int i = 0; i <= len; i++) { /* (i = 0: the hit check of a read shorter than the seed consults D_seed too, :324-328) */
-						const int si = i - (len - kp.seed_length);
-						*(uint16_t *)(rec + 8 * i + 2) = (uint16_t)((si >= 1 ? 0x80u : 0u) | (si >= 2 ? 0x8000u : 0u));
-					}
+					for (int k = -2; k < len; k++) /* (down to k = -2: the hit check, i = 0, of a read shorter than the seed consults D_seed too, :324-328) */
+						if (k - (len - kp.seed_length) >= 0) rec_put(rec, 8, k, 0x80u);
 				}
 				if (active && kp.use_precalc) /* -P: a read with an N in the last 12 bases of rc is dropped before calculate_d (inexact_match.c:129-136) */
 					for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) active = false;
@@ -495,11 +497,13 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			const int k = plen - 1 - r; /* D index */
 			{ /* D[k] is what an entry with e->i == k+1 reads as D[i-1] and one with e->i == k+2 as D[i-2] (:317,399-405) */
 				const uint32_t byte = (uint32_t)((z > 127 ? 127 : z) | ((k > 0 && nm == prev_nm) ? 0x80 : 0));
-				const int i1 = phase ? k + 1 + (len - kp.seed_length) : k + 1; /* seed: si = k+1  ->  i = si + len - seed_length */
-				uint8_t *rec = b.dbuf + (size_t)rid * b.dstride + 8 * (size_t)i1; /* what an entry with e->i == i1 needs, in one 8-byte record */
-				*(uint16_t *)(rec + (phase ? 2 : 0)) = (uint16_t)(byte | (prev_byte << 8));
-				if (!phase) rec[4] = (uint8_t)c; /* seq[len - i1]: the complement of the base the entry extends with (io.c:502-504) */
-				prev_byte = byte;
+				uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
+				rec_put(rec, phase ? 8 : 0, phase ? k + (len - kp.seed_length) : k, byte); /* (seed: its index k at the read's position k + len - seed_length) */
+				if (!phase) { /* seq[len - i1], i1 = k + 1: the complement of the base an entry at i1 extends with (io.c:502-504); four positions share 16 bits */
+					const int i1 = k + 1;
+					bacc |= (uint32_t)c << (4 * (i1 & 3));
+					if ((i1 & 3) == 3 || i1 == len) { *(uint16_t *)(rec + REC_BYTES * (i1 >> 2) + 6) = (uint16_t)bacc; bacc = 0; }
+				}
 			}
 			if (dbgD) {
 				int32_t *dst = phase ? dbgDs + ((size_t)rid * dbg_lds + k) * 2 : dbgD + ((size_t)rid * dbg_ld + k) * 2;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 					dst[0] = z + 1; dst[1] = 0;
 				}
 				if (phase == 0 && kp.seed_length && len > kp.seed_length) { /* inexact_match.c:141-143 */
-					phase = 1; plen = kp.seed_length; r = plen - 1; z = 0; prev_nm = 0; prev_byte = 0;
+					phase = 1; plen = kp.seed_length; r = plen - 1; z = 0; prev_nm = 0;
 					cL = 0; cU = last_row; curT = 1;
 					c = seq[r]; cnext = r >= 1 ? seq[r - 1] : 4;
 				} else {
@@ -742,9 +746,9 @@ template <typename P, bool WIDE> struct LHeap {
 			e.L = (P)(((uint64_t)w0.y << 32) | w0.x); e.U = (P)(((uint64_t)w0.w << 32) | w0.z);
 			e.f = w1.x; e.sa = w1.y; e.runsLo = w1.z; e.runsHi = w1.w;
 		} else {
-			e.L = (P)w0.x; e.U = (P)w0.y; e.f = w0.z; e.sa = w0.w & 0x3FFu;
+			e.L = (P)w0.x; e.U = (P)w0.y; e.f = w0.z; e.sa = w0.w & 0x3FFFFFFu; /* (state | aln_length << 2 | the one gap run << 10: ERUNS_LO; one register, not two) */
 			if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w0.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w0.w >> 29) << 32); }
-			e.runsLo = 0xFFFF0000u | ((w0.w >> 10) & 0xFFFFu); e.runsHi = 0xFFFFFFFFu;
+			e.runsLo = 0xFFFFFFFFu; e.runsHi = 0xFFFFFFFFu; /* (not used with 16-byte entries: the run is in e.sa) */
 		}
 		e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
 	}
@@ -896,6 +900,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		s_nfree = keep ? bs[2] : 0u;
 		s_active = 0; s_left = 0; s_need_sum = 0; s_need_cnt = 0;
 	}
+	/* where every slot's records are (a lane's read may belong to an earlier slot than the one this launch feeds from): in LDS, so that the
+	 * lane needs no 64-bit pointer to its read's records across the loop - its slot and read numbers name them (registers) */
+	__shared__ unsigned long long s_dbuf[BWB_MAX_SLOTS];
+	__shared__ unsigned int s_dstride[BWB_MAX_SLOTS];
+	if (threadIdx.x < BWB_MAX_SLOTS) { s_dbuf[threadIdx.x] = (unsigned long long)(uintptr_t)descs[threadIdx.x].b.dbuf; s_dstride[threadIdx.x] = descs[threadIdx.x].b.dstride; }
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
 	/* The lane's scratch areas are addressed from its slot number where they are used: `slotv` is passed through an empty asm
@@ -953,6 +962,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	                                                           reference's int num_best sum :350-352) */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
 	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
+	/* the popped entry's gap runs: four 16-bit words with 32-byte entries; with 16-byte entries the single run travels in bits 10..25 of e.sa */
+#define ERUNS_LO (WIDE ? e.runsLo : (0xFFFF0000u | ((e.sa >> 10) & 0xFFFFu)))
+#define ERUNS_HI (WIDE ? e.runsHi : 0xFFFFFFFFu)
 	/* the tail (last interval) of the current list of an exact tail lives in the registers of the popped entry's interval: the tail starts as
 	 * that interval (:345-347), and the entry's interval is not looked at again once its exact tail has begun (registers decide whether three
 	 * waves fit a SIMD) */
@@ -960,8 +972,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define cU e.U
 	h.tw = h.tw1 = h.sw = u32x4{ 0u, 0u, 0u, 0u };
 #define e_score (h.cb) /* the score of the entry being worked on = the bucket it was popped from: the cached one, which does not move until the next pop */
-	const uint2 *recs = nullptr; /* the read's per-position records {D pair, D_seed pair, base} written by kl_calc_d */
-	u32x2 rec = { 0u, 0u }; bool rec_ok = false; /* the record loaded last; it is still the one this iteration needs (set by an exact step for the step's other intervals) */
+	u32x4 rec = { 0u, 0u, 0u, 0xFFFF0000u }; /* the record loaded last; its tag (high half of .w) says which four positions it serves: a match child is at
+	                                             i - 1 and popped next, the intervals of an exact step share a position - most iterations find their record here */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
 	uint32_t n_bkt = 0, n_est = 0, n_eld = 0, n_rec = 0; /* wave-uniform: buckets fetched, heap entries stored / loaded, per-position records loaded */
@@ -996,9 +1008,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		h.num_entries = (int)a9.x; r_vis_s = a9.y; r_vis_a = a9.z; r_pop = a9.w;
 		r_push = a10.x;
 		h.tw = v4(a11); h.tw1 = v4(a12); h.sw = v4(a13);
-		if (!WIDE) e.runsHi = ~0u; /* (16-byte entries have one gap run: a constant the compiler can fold) */
-		recs = (const uint2 *)(R_descs[rd_myslot].b.dbuf + (size_t)rid * R_descs[rd_myslot].b.dstride);
-		rec_ok = false;
+		if (!WIDE) e.runsLo = e.runsHi = ~0u; /* (16-byte entries: the one gap run is part of e.sa, LHeap::unpack) */
+		rec.w = 0xFFFF0000u;
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	} else {
@@ -1041,8 +1052,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const bool unrep = len_in == BAD_LEN;
 				SET_LEN(unrep ? 0u : len_in);
 				const uint8_t *seq = b.reads + (size_t)rid * b.stride;
-				recs = (const uint2 *)(b.dbuf + (size_t)rid * b.dstride);
-				rec_ok = false;
+				rec.w = 0xFFFF0000u; /* (no record of this read yet) */
 				const int cntN = b.dbuf[(size_t)rid * b.dstride + b.dstride - 4];
 				h.reset(); /* heap_reset :540-546 (bucket states were cleared when the previous read finished) */
 				n_alns = 0; exact_mode = false; active = true;
@@ -1136,7 +1146,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			}
 			if (n_alns >= (int)sc_acap) { ovf = true; return; }
 			myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
-			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), e.runsLo, e.runsHi); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
+			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), ERUNS_LO, ERUNS_HI); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
 			n_alns++;
 		};
 
@@ -1208,20 +1218,19 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
 		const bool want_rec = need_rank || (from_pop && rd_len < kp.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
-		n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(__ballot(want_rec && !(exact_mode && rec_ok)))));
-		/* One load: D[i-1], D[i-2] | D_seed pair | seq[len - widx].  It is only ISSUED here, in place (prefetch64: see prefetch128), and
-		 * unpacked after the rank: round 3 unpacked it on the spot - a flat load, which the gather's wait for its exchange array waits for
-		 * as well - so a wave sat out the record's round trip before its gather was even issued, a round trip that the gather's own
-		 * wait covers for free. */
-		bool rec_load = false;
-		if (want_rec) {
-			if (!exact_mode) rec_ok = false; /* (a popped entry has its own position) */
-			rec_load = !rec_ok;              /* (every interval of a multi-interval exact step reads the same record: one step in four at GRCh37 scale) */
-			rec_ok = exact_mode;             /* (cleared again when the step's last interval is done) */
-		}
+		/* The record of the entry's position (D[i-1], D[i-2] | D_seed pair | seq[len - widx]: bwb_kernels.h) - the one in registers when its tag
+		 * matches, else one load.  It is only ISSUED here, in place (prefetch128), and unpacked after the rank: round 3 unpacked it on the spot
+		 * - a flat load, which the gather's wait for its exchange array waits for as well - so a wave sat out the record's round trip before
+		 * its gather was even issued, a round trip that the gather's own wait covers for free. */
+		const bool rec_load = want_rec && (rec.w >> 16) != (uint32_t)(widx >> 2);
 		{
 			const unsigned long long mr = __ballot(rec_load);
-			if (mr) prefetch64(rec, recs + widx, mr);
+			n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(mr)));
+			if (mr) { /* the read's records written by kl_calc_d: 16 bytes per four positions (bwb_kernels.h: rec_put) */
+				const uint32_t sl_ = rd_myslot;
+				const unsigned char *rb = (const unsigned char *)(uintptr_t)((Lds<unsigned long long>)&s_dbuf[0])[sl_] + (size_t)rid * ((Lds<unsigned int>)&s_dstride[0])[sl_];
+				prefetch128(rec, rb + REC_BYTES * (widx >> 2), mr);
+			}
 		}
 		if (want_rec) {
 			const P pl = (P)(iL - 1);
@@ -1235,8 +1244,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: LHeap::prefetch, ::refill) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);
 		if (want_rec) {
-			wd = rec.x & 0xFFFFu; ws = rec.x >> 16;
-			const int cf = (int)(rec.y & 0xFFu); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
+			/* bytes j, j + 1 of a record's six D bytes are D[i-2], D[i-1] for i = 4 m + j; wd / ws hold them as {D[i-1] low, D[i-2] high} */
+			const int j8 = (widx & 3) * 8;
+			const uint32_t pd = (uint32_t)(((((uint64_t)(rec.y & 0xFFFFu)) << 32) | rec.x) >> j8) & 0xFFFFu;
+			const uint32_t ps = (uint32_t)(((((uint64_t)(rec.w & 0xFFFFu)) << 32) | rec.z) >> j8) & 0xFFFFu;
+			wd = (pd >> 8) | ((pd & 255u) << 8); ws = (ps >> 8) | ((ps & 255u) << 8);
+			const int cf = (int)((rec.y >> (16 + (j8 >> 1))) & 15u); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
 		}
 		STAMP(14);
@@ -1270,7 +1283,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					P cl, cu;
 					kid(j, cl, cu);
 					u32x4 w0, w1;
-					h.pack(cl, cu, e.f, sd, e.runsLo, e.runsHi, w0, w1);
+					h.pack(cl, cu, e.f, sd & 0x3FFu, ERUNS_LO, ERUNS_HI, w0, w1);
 					if (gm) { h.store_packed(++sx, w0, w1); st_cnt++; if (!WIDE) h.sw = w0; }
 					else { h.tw = w0; h.tw1 = w1; } /* (the last child is popped next: the register mirror is its only copy) */
 				}
@@ -1365,7 +1378,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						const uint32_t f_match = (uint32_t)((e_i - 1) & 255) | ((uint32_t)e_mm << 8) | f_base;
 						const uint32_t f_mis = (uint32_t)((e_i - 1) & 255) | ((uint32_t)((e_mm + 1) & 255) << 8) | f_base;
 						const uint32_t f_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
-						const uint64_t eruns = ((uint64_t)e.runsHi << 32) | e.runsLo;
+						const uint64_t eruns = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO;
 						uint64_t gruns_i, gruns_d; /* new run on open (start = aln_length, len 1); len+1 on extend */
 						if (gap_open) {
 							const int sh = 16 * (e_go & 3);
@@ -1419,7 +1432,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								P cl, cu;
 								kid(j, cl, cu);
 								u32x4 w0, w1;
-								h.pack(cl, cu, f_match, sm, e.runsLo, e.runsHi, w0, w1);
+								h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1);
 								if (mm) { h.store_packed(++s0, w0, w1); st_cnt++; sec = w0; sec_ok = true; }
 								else { h.tw = w0; h.tw1 = w1; }
 							}
@@ -1471,7 +1484,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					swapped = true;
 					cursel = !cursel; curT = nx.T; cL = nx.tL; cU = nx.tU;
 					if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers, not from what this step has just stored) */
-					nx.T = 0; s = 0; rec_ok = false;
+					nx.T = 0; s = 0;
 					lastW = nxw; nxw = 0;
 					if (curT == 0) exact_done = true; /* :114 */
 					else { r--; if (r < (seeding ? rd_len - PRECALC_LEN : 0)) exact_done = true; }
@@ -1625,6 +1638,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 }
 
 #undef lbase
+#undef ERUNS_LO
+#undef ERUNS_HI
 #undef KARGS
 #undef R_descs
 #undef R_wk
