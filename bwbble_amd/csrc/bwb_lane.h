@@ -187,32 +187,37 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	Lds<uint32_t> xch = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF); /* [0,64): L owners, [64,128): U owners, both transposed: owner o at (o & 7) * 8 + (o >> 3) */
 	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU_MAX;
 	const uint32_t k = pi.ku - (uint32_t)first;
-	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL;
+	/* (the exchange array carries bucket << 3, the bucket's index in 16-byte slices - one add and one shift-add make the address; a bucket
+	 * number has 28 bits, NONE32 stays NONE32) */
+	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? NONE32 : pi.blkL << 3;
 	xch[64 + lane] = NONE32;
-	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU;
+	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU << 3;
 	u32x4 a0 = { NONE32, NONE32, NONE32, NONE32 }, a1 = a0;
 	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
 	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
 	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the owners are in registers, and whatever was read from the rows before (the children of
 	                                       the previous iteration, the previous round's U rows) is too */
+	/* the LDS destination of a load (M0) from a scalar copy of the wave's LDS base: no vector add and readfirstlane per load */
+	uint32_t sv = (uint32_t)(uintptr_t)stage;
+	asm volatile("" : "+v"(sv)); /* (not loop-invariant for the compiler: a scalar kept across the loop would be one more spilled SGPR) */
+	const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
-		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
-		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oL[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 64 * r), 16, 0, BWB_GATHER_AUX);
+		const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
 	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
 #pragma unroll
 	for (int r = 0; r < NU_MAX / 8; r++) {
-		const int slice = (p - ((8 * r + sub) >> 1)) & 7;
-		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)oU[r] * 8 + slice), (void __attribute__((address_space(3))) *)(stage + 512 + 64 * r), 16, 0, BWB_GATHER_AUX);
+		const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
 	                                       record, the heap entry a pop uncovered, the next list interval: all issued ahead of the gather) */
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
-
 #endif
 
 /* Rank from a 64-character bucket (bwb_device.h): acc[j] = #j among the first n (0..32) characters of the sub-block whose planes are p,
@@ -902,6 +907,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	}
 	/* where every slot's records are (a lane's read may belong to an earlier slot than the one this launch feeds from): in LDS, so that the
 	 * lane needs no 64-bit pointer to its read's records across the loop - its slot and read numbers name them (registers) */
+	__shared__ unsigned long long s_cnt[LANE_BLOCK / 64]; /* per wave: heap entries stored | fetched << 32 */
+	if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = 0ull;
 	__shared__ unsigned long long s_dbuf[BWB_MAX_SLOTS];
 	__shared__ unsigned int s_dstride[BWB_MAX_SLOTS];
 	if (threadIdx.x < BWB_MAX_SLOTS) { s_dbuf[threadIdx.x] = (unsigned long long)(uintptr_t)descs[threadIdx.x].b.dbuf; s_dstride[threadIdx.x] = descs[threadIdx.x].b.dstride; }
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	                                             i - 1 and popped next, the intervals of an exact step share a position - most iterations find their record here */
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
-	uint32_t n_bkt = 0, n_est = 0, n_eld = 0, n_rec = 0; /* wave-uniform: buckets fetched, heap entries stored / loaded, per-position records loaded */
+	uint32_t n_bkt = 0, n_rec = 0; /* wave-uniform: buckets fetched, records loaded (heap entries stored / fetched: s_cnt) */
 	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -1124,6 +1131,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (!__any(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
 
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
+#ifdef BWB_PERTURB_VALU /* measurement only: what does the loop pay for 128 more vector instructions per iteration? (profiles/r4_ab_steps.txt) */
+		asm volatile(".rept 128\n\tv_nop\n\t.endr");
+#endif
+#ifdef BWB_PERTURB_SALU
+		asm volatile(".rept 128\n\ts_nop 0\n\t.endr");
+#endif
 		uint32_t ld_cnt = 0; /* heap entries this lane fetches from memory in this iteration */
 		uint32_t pf_top = NONE32, pf_hdr = NONE32, pf_free = NONE32; /* what LHeap::pop wants fetched ahead of the gather; the chunk it emptied */
 		P iL = 0, iU = 0;
@@ -1570,8 +1583,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		HIST(H_TOP_RELOAD, ld_cnt != 0);
 		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
-		n_eld = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_eld + wave_sum5(ld_cnt)));
-		n_est = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_est + wave_sum5(st_cnt > 31u ? 31u : st_cnt)));
+		/* heap entries stored (low half) and fetched (high half) by the wave: one LDS atomic per iteration (round 3 summed each of the two
+		 * per-lane counts over the wave with five ballots: fifty instructions of an issue-bound loop, profiles/r4_ab_steps.txt session 7) */
+		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[threadIdx.x >> 6], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		STAMP(5);
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);
@@ -1610,7 +1624,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 	}
 	if (lane == 0 && n_bkt) atomicAdd(&R_stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
-	if (lane == 0) { atomicAdd(&R_stats[STAT_ENT_ST], (unsigned long long)n_est); atomicAdd(&R_stats[STAT_ENT_LD], (unsigned long long)n_eld); atomicAdd(&R_stats[STAT_REC_LD], (unsigned long long)n_rec); }
+	if (lane == 0) { const unsigned long long sc_ = __hip_atomic_load((Lds<unsigned long long>)&s_cnt[threadIdx.x >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&R_stats[STAT_ENT_ST], sc_ & 0xFFFFFFFFull); atomicAdd(&R_stats[STAT_ENT_LD], sc_ >> 32); atomicAdd(&R_stats[STAT_REC_LD], (unsigned long long)n_rec); }
 	if (parked) atomicAdd(&R_stats[STAT_PARKED], 1ull);
 	if (lane == 0) {
 		atomicAdd(&R_stats[STAT_N], (unsigned long long)n_iter);            /* loop iterations of busy lanes */
