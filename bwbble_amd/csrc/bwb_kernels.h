@@ -110,6 +110,18 @@ template <typename P> __device__ __forceinline__ void load_base(P *s_base, const
 	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = (P)ix.base[t >> 4][t & 15];
 	__syncthreads();
 }
+/* the base table twice: as it is (exact counts: O(), bwt.c:348-372), then O_alphabet's view of it (bwt.c:423-437): in a superblock's row the
+ * codes 5, 9, 11, 13 - never counted there - have C[j] - 1, to which the rank adds 1 - [first char of the block == j] (bwb_lane.h: side_finish);
+ * the rows of the special positions -1 and length-1 are exact in both */
+template <typename P> __device__ __forceinline__ void load_base2(P *s_base, const DevIndex &ix) {
+	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) {
+		const int row = t >> 4, j = t & 15;
+		const P v = (P)ix.base[row][j];
+		s_base[t] = v;
+		s_base[BWB_BASE_ROWS * 16 + t] = (row < BWB_NSB_MAX && ((0x2A20u >> j) & 1u)) ? (P)(ix.base[BWB_ROW_NEG][j] - 1) : v;
+	}
+	__syncthreads();
+}
 
 /* ============================================================================================
  * Index re-layout: reference arrays (bwt words io.c:590-609, O rows bwt.c:280-291) -> buckets

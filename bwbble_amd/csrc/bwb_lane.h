@@ -88,7 +88,8 @@ struct LaneScratch {
 #define WAVE_LDS_BYTES (WAVE_XCH_OFF + 512)
 /* block-level LDS in front of the waves' areas: the base table, then one all-zero 128-byte row that stands in for the bucket of a
  * position that needs none (-1, length-1, an idle lane): counts 0, no characters */
-#define LDS_ZERO_OFF (BWB_BASE_ROWS * 16 * 8)
+/* (two base tables of BWB_BASE_ROWS rows: the exact one, then O_alphabet's view of it - load_base2 -; kl_calc_d only reads the first) */
+#define LDS_ZERO_OFF (2 * BWB_BASE_ROWS * 16 * 8)
 #define LDS_WAVES_OFF (LDS_ZERO_OFF + 128)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
@@ -247,43 +248,44 @@ __device__ __forceinline__ void side_read(Lds<u32x4> row, int rot, int off, Side
 	sb.first = ((Lds<uint32_t>)(row + ((7 + rot) & 7)))[0];
 	sb.n = (off & 31) + 1;
 }
-/* rel = counts (slices 0-3 of `cnt_row`) + mid + pass -> slices `dst0` .. `dst0 + 3` of the lane's own row; `quirk`: O_alphabet's view of 5, 9, 11, 13 */
+/* rel[j] = count of j before the bucket (slices 0-3 of `cnt_row`, count-slice order) + mid + pass, for j = 0..15 IN CODE ORDER -> slices
+ * `dst0` .. `dst0 + 3` of the lane's own row (slice k holds the codes 4k .. 4k+3: kid_get finds code j with three instructions; round 3
+ * left them in the count-slice order, whose address arithmetic cost more than the rank's adds); `quirk`: O_alphabet's view of 5, 9, 11, 13.
+ * Every count slice is read before the first result is written: the row is source and destination. */
 __device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const SideBits &sb, bool quirk, Lds<u32x4> own, int rot, int dst0) {
 	uint32_t acc[16];
 	sub_pops16(sb.planes, sb.n, acc);
 	const uint32_t md[4] = { sb.mid.x, sb.mid.y, sb.mid.z, sb.mid.w };
 #pragma unroll
-	for (int s = 0; s < 4; s++) {
-		u32x4 q = cnt_row[(s + crot) & 7];
-		q.x += acc[2 * s] + (md[s] & 255u); q.y += acc[2 * s + 1] + ((md[s] >> 8) & 255u);
-		q.z += acc[2 * s + 8] + ((md[s] >> 16) & 255u); q.w += acc[2 * s + 9] + (md[s] >> 24);
-		if (quirk) { /* (codes 5, 9, 11, 13 are components {2,y}, {0,w}, {1,w}, {2,w}) */
-			if (s == 2) q.y = sb.first == 5u ? 0u : 1u;
-			if (s == 0) q.w = sb.first == 9u ? 0u : 1u;
-			if (s == 1) q.w = sb.first == 11u ? 0u : 1u;
-			if (s == 2) q.w = sb.first == 13u ? 0u : 1u;
-		}
-		own[(dst0 + s + rot) & 7] = q;
+	for (int s = 0; s < 4; s++) { /* (slice s = the codes 2s, 2s+1, 2s+8, 2s+9) */
+		const u32x4 q = cnt_row[(s + crot) & 7];
+		acc[2 * s] += q.x + (md[s] & 255u); acc[2 * s + 1] += q.y + ((md[s] >> 8) & 255u);
+		acc[2 * s + 8] += q.z + ((md[s] >> 16) & 255u); acc[2 * s + 9] += q.w + (md[s] >> 24);
 	}
+	if (quirk) { acc[5] = sb.first == 5u ? 0u : 1u; acc[9] = sb.first == 9u ? 0u : 1u; acc[11] = sb.first == 11u ? 0u : 1u; acc[13] = sb.first == 13u ? 0u : 1u; }
+#pragma unroll
+	for (int k = 0; k < 4; k++) own[(dst0 + k + rot) & 7] = u32x4{ acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3] };
 }
 /* index of code j in the count-slice order */
 __device__ __forceinline__ constexpr int cslot(int j) { return 4 * ((j & 7) >> 1) + (j & 1) + 2 * (j >> 3); }
 
 /* where a lane's children are after wave_children */
 template <typename P> struct KidCtx {
-	Lds<uint32_t> row;     /* the lane's row: relL in slices 0-3, relU in slices 4-7 (count-slice order, rotated) */
+	Lds<uint32_t> row;     /* the lane's row: relL in slices 0-3, relU in slices 4-7 (code order: slice k = codes 4k .. 4k+3; rotated by the lane's rot) */
 	int rot;
 	Lds<P> baseL, baseU;   /* base-table rows of the two positions */
 	bool qL, qU;           /* O_alphabet's view of the codes 5, 9, 11, 13 applies to this side: value = C[j] - [first char of the block == j] */
 };
 /* child j = [vL(j) + 1, vU(j)] */
 template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &kc, Lds<P> s_base, int j, P &L, P &U) {
-	const int s = (j & 7) >> 1, t = (j & 1) + 2 * (j >> 3);
-	const uint32_t rl = kc.row[4 * ((s + kc.rot) & 7) + t], ru = kc.row[4 * ((4 + s + kc.rot) & 7) + t];
-	const bool qz = ((QUIRK_CODES >> j) & 1u) != 0;
-	const bool zl = qz && kc.qL, zu = qz && kc.qU; /* rel = 1 - [first == j] then; the base is C[j] - 1 */
-	const Lds<P> cneg = s_base + BWB_ROW_NEG * 16;
-	const P bL = (zl ? cneg : kc.baseL)[j] - (zl ? 1 : 0), bU = (zu ? cneg : kc.baseU)[j] - (zu ? 1 : 0);
+	/* code j: component j & 3 of slice (j >> 2) + rot (mod 8); relU four slices on, i.e. the same byte offset with bit 6 flipped */
+	const uint32_t x = (uint32_t)j << 2;
+	const uint32_t offL = ((((x & 0x30u) + ((uint32_t)kc.rot << 4)) & 0x70u) | (x & 0xCu));
+	const uint32_t rl = *(Lds<uint32_t>)((LdsBytes)kc.row + offL), ru = *(Lds<uint32_t>)((LdsBytes)kc.row + (offL ^ 0x40u));
+	/* (O_alphabet's view of the codes 5, 9, 11, 13 - value = C[j] - [first char of the block == j] - needs nothing here: side_finish left
+	 * rel = 1 - [first == j] and the side's base row is one of the second table, whose entries for these codes are C[j] - 1: load_base2) */
+	(void)s_base;
+	const P bL = kc.baseL[j], bU = kc.baseU[j];
 	L = (P)(bL + (P)rl + 1); U = (P)(bU + (P)ru);
 }
 
@@ -306,8 +308,8 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	const Lds<u32x4> own = stage + lane * 8;
 	const int rot = (lane >> 1) & 7;
 	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
-	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
+	kc.baseL = s_base + pi.rowL * 16 + (kc.qL ? BWB_BASE_ROWS * 16 : 0); kc.baseU = s_base + pi.rowU * 16 + (kc.qU ? BWB_BASE_ROWS * 16 : 0);
 	/* Both sides are independent one-pass ranks.  A lane's own row is source (counts 0-3, planes and mid counts 4-7: side L, and side U of
 	 * a pair in one bucket) and destination (relL -> 0-3, relU -> 4-7): what side L needs from the upper half goes to registers first,
 	 * then side U is finished (it still finds the counts in the lower half), then side L. */
@@ -337,11 +339,11 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 			}
 			if (first + NU_MAX >= pi.nU) break;
 		}
-		/* non-empty children, when both positions have the same base row: relU > relL (component t of slice s is code {2s, 2s+1, 2s+8, 2s+9}[t]) */
+		/* non-empty children, when both positions have the same base row: relU > relL (slice k holds the codes 4k .. 4k+3) */
 #pragma unroll
-		for (int s = 0; s < 4; s++) {
-			const u32x4 l = own[(s + rot) & 7], q = own[(4 + s + rot) & 7];
-			ne |= (q.x > l.x ? 1u : 0u) << (2 * s) | (q.y > l.y ? 1u : 0u) << (2 * s + 1) | (q.z > l.z ? 1u : 0u) << (2 * s + 8) | (q.w > l.w ? 1u : 0u) << (2 * s + 9);
+		for (int k = 0; k < 4; k++) {
+			const u32x4 l = own[(k + rot) & 7], q = own[(4 + k + rot) & 7];
+			ne |= (q.x > l.x ? 1u : 0u) << (4 * k) | (q.y > l.y ? 1u : 0u) << (4 * k + 1) | (q.z > l.z ? 1u : 0u) << (4 * k + 2) | (q.w > l.w ? 1u : 0u) << (4 * k + 3);
 		}
 	}
 	const bool rows_differ = need && pi.rowL != pi.rowU;
@@ -598,8 +600,8 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t fhead;        /* chunks emptied by pops during this read (LIFO through header .x) */
 	uint32_t fl_c;         /* the chunk an allocation of THIS iteration took from that list (NONE32: none): its header holds the new head, which
 	                          refill() fetches in place at the end of the iteration - it lands under the next iteration's gather wait */
-	uint32_t pblk, pused, keep;  /* the lane's private run of `keep` consecutive chunks starts at chunk (pblk + threadIdx.x) * keep (pblk: wave-uniform); how
-	                                many of them this read has taken */
+	uint32_t pblk, pused, keep;  /* the lane's private run of `keep` consecutive chunks starts at chunk (pblk + lane in wave) * keep (pblk: wave-uniform,
+	                                the wave's first lane in its region); how many of them this read has taken */
 	uint32_t pshared;            /* first chunk of the region's shared part (after every lane's private run) */
 	uint32_t xhead;              /* chunks the current read took beyond the private chain: the chain's head (the chunk taken last).  Its tail
 	                                (the first one: a constant once set) and the chain's length live in memory - words 0 and 1 of the lane's
@@ -691,7 +693,7 @@ template <typename P, bool WIDE> struct LHeap {
 		 * inside this divergent branch, and the wave sat out that round trip in almost every iteration (some lane allocates).
 		 * FRESH: the first allocation of a read (loop top): the list is empty by construction and the register may be in flight. */
 		if (!FRESH && fhead != NONE32) { const uint32_t c = fhead; fl_c = c; fhead = NONE32; return c; }
-		if (pused < keep) return (pblk + threadIdx.x) * keep + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
+		if (pused < keep) return (pblk + __lane_id()) * keep + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
 		uint32_t c = NONE32;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		while ((uint32_t)old != NONE32) {
@@ -759,14 +761,14 @@ template <typename P, bool WIDE> struct LHeap {
 	}
 	__device__ __forceinline__ void store_packed(uint32_t st, const u32x4 w0, const u32x4 w1) const {
 		typedef __attribute__((address_space(1))) u32x4 *G4;
-		G4 p = (G4)(uintptr_t)(chunk_ptr(st >> 6) + (st & 63u) * (WIDE ? 2 : 1));
+		G4 p = (G4)(uintptr_t)(pool + (size_t)st * (WIDE ? 2 : 1)); /* (a state word is the slot's index in the pool: chunk << 6 | fill) */
 		p[0] = w0;
 		if (WIDE) p[1] = w1;
 	}
 	/* the entry at state st -> tw (tw1): issued, not waited for - the words are first looked at by the pop that unpacks them */
 	__device__ __forceinline__ void load_top(uint32_t st) {
 		typedef const __attribute__((address_space(1))) u32x4 *G4;
-		G4 p = (G4)(uintptr_t)(chunk_ptr(st >> 6) + (st & 63u) * (WIDE ? 2 : 1));
+		G4 p = (G4)(uintptr_t)(pool + (size_t)st * (WIDE ? 2 : 1));
 		tw = p[0];
 		if (WIDE) tw1 = p[1];
 		top_valid = true;
@@ -891,7 +893,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define R_sc(f) (KARGS->sc.f)
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
-	const int lane = (int)(threadIdx.x & 63u);
 	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
 	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(LdsBytes)(smem + LDS_ZERO_OFF);
 	const Lds<P> sb = (Lds<P>)(LdsBytes)smem; /* the base table again, as an LDS pointer */
@@ -913,12 +914,16 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	__shared__ unsigned int s_dstride[BWB_MAX_SLOTS];
 	if (threadIdx.x < BWB_MAX_SLOTS) { s_dbuf[threadIdx.x] = (unsigned long long)(uintptr_t)descs[threadIdx.x].b.dbuf; s_dstride[threadIdx.x] = descs[threadIdx.x].b.dstride; }
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
-	load_base<P>(s_base, ix);
+	load_base2<P>(s_base, ix);
 	/* The lane's scratch areas are addressed from its slot number where they are used: `slotv` is passed through an empty asm
 	 * statement in every iteration, so the compiler cannot keep six 64-bit pointers alive across the loop (registers are what
 	 * decides whether three waves fit a SIMD). */
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	uint32_t slotv = slot;
+	/* the lane's number in its wave and in its block, taken from slotv where they are used (one v_and): a value derived from threadIdx.x at the
+	 * top of the kernel would be one more register across the loop - or, as it was, a spilled one fetched from scratch in front of every gather */
+#define lane ((int)(slotv & 63u))
+#define tid_in_block (slotv & (uint32_t)(LANE_BLOCK - 1))
 	/* The bases and sizes of the lane's scratch areas that the loop uses in (almost) every iteration, made OPAQUE scalar values: with more
 	 * wave-uniform values alive than scalar registers, the compiler drops kernel arguments and loads them again from the kernarg segment
 	 * where they are used - an s_load and a full wait on the scalar cache, five times per iteration in the first round-4 kernel
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 	LHeap<P, WIDE> h;
 	const uint32_t region = blockIdx.x % sc.n_regions;
-	h.pblk = (blockIdx.x / sc.n_regions) * LANE_BLOCK;
+	h.pblk = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x / sc.n_regions) * LANE_BLOCK + (threadIdx.x & ~63u)));
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow; h.nslots = sc.nslots;
 	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
@@ -1037,7 +1042,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const uint32_t left = used < h.pool_cap ? h.pool_cap - used : 0u;
 				const uint32_t blocks_in_region = (gridDim.x + sc.n_regions - 1) / sc.n_regions;
 				const uint32_t avail = s_nfree + left / blocks_in_region;
-				const uint32_t mine = __popcll(__ballot(true) & ((1ull << (threadIdx.x & 63u)) - 1ull));
+				const uint32_t mine = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
 				/* what a read is expected to take: four times the mean of the reads this block has finished (the needs are heavy-tailed;
 				 * 150 bp reads with -n 5 average 1 750 chunks at GRCh37 scale, 100 bp reads with -n 3 a third of that), at least 1 MB */
 				const uint32_t cnt = s_need_cnt, per = cnt ? (uint32_t)(((unsigned long long)s_need_sum * 64ull) / cnt) : 0u;
@@ -1585,7 +1590,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
 		/* heap entries stored (low half) and fetched (high half) by the wave: one LDS atomic per iteration (round 3 summed each of the two
 		 * per-lane counts over the wave with five ballots: fifty instructions of an issue-bound loop, profiles/r4_ab_steps.txt session 7) */
-		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[threadIdx.x >> 6], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[tid_in_block >> 6], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		STAMP(5);
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);
@@ -1652,6 +1657,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 }
 
 #undef lbase
+#undef lane
+#undef tid_in_block
 #undef ERUNS_LO
 #undef ERUNS_HI
 #undef KARGS
