@@ -364,8 +364,8 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 			 * wait for another one to leave would find the cursor exhausted and park again at once.  So never more blocks per CU than
 			 * the runtime says fit (registers, LDS). */
 			int occ = 0;
-			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true> : (const void *)kl_search<uint32_t, false>)
-			                          : (c->wide ? (const void *)kl_search<uint64_t, true> : (const void *)kl_search<uint64_t, false>);
+			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true, true> : (const void *)kl_search<uint32_t, false, true>)
+			                          : (c->wide ? (const void *)kl_search<uint64_t, true, true> : (const void *)kl_search<uint64_t, false, true>); /* (the -S instantiations need no more) */
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
 				if (c->dbg && !s.ready) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU\n", occ, LANE_BLOCK);
 				c->bpc_search = std::min(c->bpc_search, occ);
@@ -638,10 +638,13 @@ static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 	HIPCHK(hipEventRecord(e0, c->stream));
 	const SlotDesc *descs = c->d_descs.as<SlotDesc>();
 	unsigned long long *st = c->d_stats.as<unsigned long long>();
-	if (c->pos32 && !c->wide) hipLaunchKernelGGL((kl_search<uint32_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
-	else if (c->pos32) hipLaunchKernelGGL((kl_search<uint32_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
-	else if (!c->wide) hipLaunchKernelGGL((kl_search<uint64_t, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
-	else hipLaunchKernelGGL((kl_search<uint64_t, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st);
+#define LAUNCH_SEARCH(PT, W, M) hipLaunchKernelGGL((kl_search<PT, W, M>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st)
+	const bool multi = c->kp.multiref != 0;
+	if (c->pos32 && !c->wide) { if (multi) LAUNCH_SEARCH(uint32_t, false, true); else LAUNCH_SEARCH(uint32_t, false, false); }
+	else if (c->pos32) { if (multi) LAUNCH_SEARCH(uint32_t, true, true); else LAUNCH_SEARCH(uint32_t, true, false); }
+	else if (!c->wide) { if (multi) LAUNCH_SEARCH(uint64_t, false, true); else LAUNCH_SEARCH(uint64_t, false, false); }
+	else { if (multi) LAUNCH_SEARCH(uint64_t, true, true); else LAUNCH_SEARCH(uint64_t, true, false); }
+#undef LAUNCH_SEARCH
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(e1, c->stream));
 	if (k == 0) {

@@ -597,9 +597,10 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t pool_cap;
 	uint32_t *bstate;      /* this lane's row: bstate[s] */
 	uint32_t nslots;
-	uint32_t fhead;        /* chunks emptied by pops during this read (LIFO through header .x) */
-	uint32_t fl_c;         /* the chunk an allocation of THIS iteration took from that list (NONE32: none): its header holds the new head, which
-	                          refill() fetches in place at the end of the iteration - it lands under the next iteration's gather wait */
+	uint32_t fhead;        /* chunks emptied by pops during this read (LIFO through header .x): the list's head.  With FHEAD_TAKEN set: the chunk
+	                          an allocation took from the list - the new head is in ITS header and is fetched, in place, with the next
+	                          iteration's prefetches (LHeap::prefetch), ahead of the gather; until then the list counts as empty */
+#define FHEAD_TAKEN 0x80000000u /* (a chunk number has 26 bits; NONE32 has this bit too: test for NONE32 first) */
 	uint32_t pblk, pused, keep;  /* the lane's private run of `keep` consecutive chunks starts at chunk (pblk + lane in wave) * keep (pblk: wave-uniform,
 	                                the wave's first lane in its region); how many of them this read has taken */
 	uint32_t pshared;            /* first chunk of the region's shared part (after every lane's private run) */
@@ -646,7 +647,7 @@ template <typename P, bool WIDE> struct LHeap {
 		return w;
 	}
 	__device__ __forceinline__ uint4 *chunk_ptr(uint32_t c) const { return pool + (size_t)c * (CHUNK_SLOTS * (WIDE ? 2 : 1)); }
-	__device__ __forceinline__ void reset() { /* (fhead is NONE32 already: set when the previous read finished - not here, where a refill may still be in flight) */ pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; sec_valid = false; cprev = 0; stX = stGo = stGe = NONE32; }
+	__device__ __forceinline__ void reset() { /* (fhead is NONE32 already: set when the previous read finished) */ pused = 0; neW = 0; cb = 0; cst = NONE32; num_entries = 0; top_valid = false; sec_valid = false; cprev = 0; stX = stGo = stGe = NONE32; }
 	/* which register holds the state of the side bucket at distance `pen` (a wave-uniform penalty) from cb: 0 = cb itself (zero penalty),
 	 * 1 = stX, 2 = stGo, 3 = stGe.  Equal penalties share the first register of the order X, Go, Ge. */
 	__device__ __forceinline__ int side_of(int pen) const { return pen == 0 ? 0 : (pen == pX ? 1 : (pen == pGo ? 2 : 3)); }
@@ -688,11 +689,11 @@ template <typename P, bool WIDE> struct LHeap {
 	 * flight need, not the worst case every lane has ever seen. */
 	template <bool FRESH = false, typename XS> __device__ __forceinline__ uint32_t alloc(bool &ovf, XS xs) {
 		/* The list of emptied chunks: its head is in a register, the rest is linked through the chunks' headers.  Taking the head
-		 * leaves the list EMPTY for the rest of the iteration; the new head (a load from the taken chunk's header) is fetched by
-		 * refill() where the lanes have met again, in place, and lands under the next iteration's gather wait: round 3 loaded it here,
-		 * inside this divergent branch, and the wave sat out that round trip in almost every iteration (some lane allocates).
-		 * FRESH: the first allocation of a read (loop top): the list is empty by construction and the register may be in flight. */
-		if (!FRESH && fhead != NONE32) { const uint32_t c = fhead; fl_c = c; fhead = NONE32; return c; }
+		 * leaves the list EMPTY for the rest of the iteration (fhead = the taken chunk | FHEAD_TAKEN); the new head (a load from the
+		 * taken chunk's header) is fetched with the next iteration's prefetches, in place, and lands under that iteration's gather wait:
+		 * round 3 loaded it here, inside this divergent branch, and the wave sat out that round trip in almost every iteration (some
+		 * lane allocates).  FRESH: the first allocation of a read (loop top): the list is empty by construction. */
+		if (!FRESH && fhead < FHEAD_TAKEN) { const uint32_t c = fhead; fhead = c | FHEAD_TAKEN; return c; }
 		if (pused < keep) return (pblk + __lane_id()) * keep + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
 		uint32_t c = NONE32;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -804,16 +805,9 @@ template <typename P, bool WIDE> struct LHeap {
 		else top_valid = false;
 		num_entries--;
 	}
-	/* the chunk a pop emptied goes onto the lane's list (after the gather's wait: the head register is valid again) */
+	/* the chunk a pop emptied goes onto the lane's list (after the gather's wait: a head that was being fetched is there) */
 	__device__ __forceinline__ void give_back(uint32_t c) {
 		if (c != NONE32) { ((__attribute__((address_space(1))) uint32_t *)(uintptr_t)chunk_ptr(c))[0] = fhead; fhead = c; }
-	}
-	/* the new head of the list of emptied chunks, when an allocation of this iteration took the old one (every lane of the wave calls
-	 * this, in uniform control flow; see prefetch128 for the rule) */
-	__device__ __forceinline__ void refill() {
-		const unsigned long long m = __ballot(fl_c != NONE32);
-		if (m) prefetch32(fhead, (const uint32_t *)chunk_ptr(fl_c), m);
-		fl_c = NONE32;
 	}
 	/* issues what pop() asked for (every lane of the wave calls this, in uniform control flow) */
 	__device__ __forceinline__ void prefetch(uint32_t pf_top, uint32_t pf_hdr) {
@@ -824,6 +818,10 @@ template <typename P, bool WIDE> struct LHeap {
 			if (WIDE) prefetch128(tw1, src + 1, mt);
 		}
 		if (mh) prefetch32(cprev, (const uint32_t *)chunk_ptr(pf_hdr) + 1, mh);
+		/* the new head of the list of emptied chunks, when an allocation of the previous iteration took the old one */
+		const bool taken = fhead != NONE32 && (fhead & FHEAD_TAKEN) != 0u;
+		const unsigned long long mf = __ballot(taken);
+		if (mf) prefetch32(fhead, (const uint32_t *)chunk_ptr(fhead & ~FHEAD_TAKEN), mf);
 	}
 };
 
@@ -876,7 +874,9 @@ enum { H_ITER = 0, H_POP, H_POP_FROM_MIRROR, H_POP_GAPPED, H_PRUNED, H_HIT, H_EX
  * register of the per-lane state machine goes to the lane's save area, the heap, lists and hits are in the lane's global
  * scratch anyway - and leaves; the next launch (which starts the next batch) resumes them in the same lanes.  A parked read
  * belongs to an earlier slot than the reads its wave starts next, hence the per-lane `myslot` and the slot table. */
-template <typename P, bool WIDE>
+/* MULTI: the multi-genome alphabet (is_multiref; false = -S).  A template parameter, not a look at MULTI: the choice sits in every
+ * trip of the child loops (the -S children are rows 1..4 mapped back to their codes), and the loop is bound by instruction issue. */
+template <typename P, bool WIDE, bool MULTI>
 __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
 	/* The kernel arguments that only rare paths use (starting, parking and finishing a read, the statistics) are read from the kernarg
 	 * segment where they are used - the pointer goes through an empty asm, so the loads cannot be hoisted out of the loop - instead of
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow; h.nslots = sc.nslots;
 	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.pX = kp.mm_score; h.pGo = kp.gapo_score; h.pGe = kp.gape_score; h.nbk = nb;
-	h.fhead = NONE32; h.fl_c = NONE32;
+	h.fhead = NONE32;
 	h.reset();
 
 	bool active = false, done = false;
@@ -1106,7 +1106,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (wk.slice_iters && w_iter >= wk.slice_iters) park = true;
 		if (__any(park)) {
 			/* ---- end of the slice for this wave: park the reads under way (word 0 of the save area tells the next launch) ---- */
-			__builtin_amdgcn_s_waitcnt(0x0F70); /* (a refill of the free list's head may be in flight: it is saved below) */
 			if (active) {
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* (lanes of other waves may be waiting for admission) */
 				auto lo = [](P v) { return (uint32_t)v; };
@@ -1192,12 +1191,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					widx = (int)(e.f & 255u);
 					if (is_group) { /* the children are those of the parent's O_alphabet call (:382-383) */
 						h.num_entries++;
-						need_rank = true; iL = e.L; iU = e.U; alpha = kp.multiref != 0;
+						need_rank = true; iL = e.L; iU = e.U; alpha = MULTI;
 					} else if (widx > 0) {
 						need_rank = true; iL = e.L; iU = e.U;
 						/* an entry with no difference left goes to the exact tail (exact counts); any other one is expanded
 						 * with O_alphabet (:345,382) */
-						alpha = kp.multiref && (rd_max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0;
+						alpha = MULTI && (rd_max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0;
 					}
 				}
 			}
@@ -1259,7 +1258,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		KidCtx<P> kc;
 		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
-		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: LHeap::prefetch, ::refill) has landed, also when no lane needed a rank */
+		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: the record, LHeap::prefetch) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);
 		if (want_rec) {
 			/* bytes j, j + 1 of a record's six D bytes are D[i-2], D[i-1] for i = 4 m + j; wd / ws hold them as {D[i-1] low, D[i-2] high} */
@@ -1279,9 +1278,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const int wG = e_state == STATE_M ? h.side_of(kp.gapo_score) : h.side_of(kp.gape_score); /* which register is the gap bucket's (0: the cached bucket itself) */
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
-		if (!kp.multiref) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
+		if (!MULTI) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
 		uint32_t st_cnt = 0; /* heap entries this lane stores in this iteration */
-		auto kid = [&](int j, P &L, P &U) { kid_get<P>(kc, sb, kp.multiref ? j : (int)((0x173Fu >> (4 * (j - 1))) & 15u), L, U); };
+		auto kid = [&](int j, P &L, P &U) { kid_get<P>(kc, sb, MULTI ? j : (int)((0x173Fu >> (4 * (j - 1))) & 15u), L, U); };
 		STAMP(3);
 
 		/* ---- C: act on it ---- */
@@ -1362,7 +1361,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
 					const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
 					const bool mm_ok = allow_diff && allow_mm;
-					const uint32_t mem = cr > 3 ? 0u : (kp.multiref ? member_mask(cr) : 2u << cr);
+					const uint32_t mem = cr > 3 ? 0u : (MULTI ? member_mask(cr) : 2u << cr);
 					/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
 					const uint32_t delm = del_ok ? ne : 0u;
 					const uint32_t mgrp = mm_ok ? ne : (ne & mem);
@@ -1487,7 +1486,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
 			else {
 				if (!seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
-				uint32_t nm = ne & (kp.multiref ? member_mask(cr) : 2u << cr);
+				uint32_t nm = ne & (MULTI ? member_mask(cr) : 2u << cr);
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;
@@ -1584,7 +1583,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 
 		STAMP(15);
-		h.refill(); /* (the lanes have met again) */
 		HIST(H_TOP_RELOAD, ld_cnt != 0);
 		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
@@ -1595,7 +1593,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);
 		if (finish) {
-			__builtin_amdgcn_s_waitcnt(0x0F70); /* (a refill of the free list's head may be in flight: the register is cleared below) */
 			h.fhead = NONE32;
 			const SlotDesc &d = R_descs[rd_myslot]; /* (the read may belong to an earlier slot than the one this launch feeds from) */
 			const OutBuf out = d.out;

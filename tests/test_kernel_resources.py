@@ -21,7 +21,7 @@ def compiled():
 
 def test_prefetched_registers_are_not_read_before_the_wait(compiled):
     res, _ = compiled
-    assert len(res) == 4  # <u32|u64> x <16|32-byte entries>
+    assert len(res) == 8  # <u32|u64 positions> x <16|32-byte entries> x <multi-genome | -S>
     for k, (sites, errs) in res.items():
         assert sites >= 2, k  # the uncovered heap entry and the chunk header word
         assert not errs, errs
@@ -31,7 +31,7 @@ def test_prefetched_registers_in_the_test_build():
     """the small-superblock test build (make testlib) is a different compilation: the same proof for it"""
     import check_prefetch_regs as cpr
     res, _ = cpr.check_all(["-DBWB_SB_SHIFT=13", "-DBWB_TEST_POS_BIAS=0x500000000ull"])
-    assert len(res) == 4
+    assert len(res) == 8
     for k, (sites, errs) in res.items():
         assert sites >= 2 and not errs, (k, errs)
 
@@ -39,10 +39,10 @@ def test_prefetched_registers_in_the_test_build():
 def test_search_kernel_register_budget(compiled):
     _, remarks = compiled
     ks = {k: v for k, v in remarks.items() if "kl_search" in k}
-    assert len(ks) == 4
+    assert len(ks) == 8
     for k, ru in ks.items():
         assert ru["Occupancy"] >= 3 and ru["VGPRs"] <= 168, (k, ru)
-    head = [v for k, v in ks.items() if "kl_searchImLb0E" in k][0]  # 64-bit positions (GRCh37 scale), 16-byte heap entries (-o <= 1)
+    head = [v for k, v in ks.items() if "kl_searchImLb0ELb1E" in k][0]  # 64-bit positions (GRCh37 scale), 16-byte heap entries (-o <= 1), multi-genome
     assert head["ScratchSize"] == 0 and head["VGPRs Spill"] == 0, head
 
 
