@@ -162,19 +162,21 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	uint32_t sv = (uint32_t)(uintptr_t)stage;
 	asm volatile("" : "+v"(sv)); /* (not loop-invariant for the compiler: a scalar kept across the loop would be one more spilled SGPR) */
 	const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
+	/* slice of instruction r = (p - ((8 r + sub) >> 1)) & 7 = (p - (sub >> 1) - 4 r) & 7: two values, for even and for odd r */
+	const uint32_t sl0 = (uint32_t)((p - (sub >> 1)) & 7), sl1 = sl0 ^ 4u;
 	const int nUr = pi.nU - first; /* (wave-uniform) U owners of this round: those beyond NU_MAX wait for the next */
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 	if (first == 0) {
 #pragma unroll
 		for (int r = 0; r < 8; r++) {
-			const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+			const uint32_t slice = (r & 1) ? sl1 : sl0;
 			__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
 		}
 	}
 	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
 #pragma unroll
 	for (int r = 0; r < NU_MAX / 8; r++) {
-		const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+		const uint32_t slice = (r & 1) ? sl1 : sl0;
 		if (8 * r < nUr) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
@@ -202,16 +204,18 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	uint32_t sv = (uint32_t)(uintptr_t)stage;
 	asm volatile("" : "+v"(sv)); /* (not loop-invariant for the compiler: a scalar kept across the loop would be one more spilled SGPR) */
 	const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
+	/* slice of instruction r = (p - ((8 r + sub) >> 1)) & 7 = (p - (sub >> 1) - 4 r) & 7: two values, for even and for odd r */
+	const uint32_t sl0 = (uint32_t)((p - (sub >> 1)) & 7), sl1 = sl0 ^ 4u;
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
-		const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+		const uint32_t slice = (r & 1) ? sl1 : sl0;
 		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
 	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
 #pragma unroll
 	for (int r = 0; r < NU_MAX / 8; r++) {
-		const uint32_t slice = (uint32_t)((p - ((8 * r + sub) >> 1)) & 7);
+		const uint32_t slice = (r & 1) ? sl1 : sl0;
 		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
@@ -694,7 +698,12 @@ template <typename P, bool WIDE> struct LHeap {
 		 * round 3 loaded it here, inside this divergent branch, and the wave sat out that round trip in almost every iteration (some
 		 * lane allocates).  FRESH: the first allocation of a read (loop top): the list is empty by construction. */
 		if (!FRESH && fhead < FHEAD_TAKEN) { const uint32_t c = fhead; fhead = c | FHEAD_TAKEN; return c; }
-		if (pused < keep) return (pblk + __lane_id()) * keep + pused++; /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
+		if (pused < keep) { /* (laying the runs of a block out chunk-major, for page locality, measured no different) */
+			uint32_t z = 0u;
+			asm volatile("" : "+v"(z)); /* (the lane number is made here, from an opaque zero: as a loop invariant it would take a register across the loop - or a scratch slot) */
+			const uint32_t lid = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+			return (pblk + lid) * keep + pused++;
+		}
 		uint32_t c = NONE32;
 		unsigned long long old = __hip_atomic_load(blockfree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		while ((uint32_t)old != NONE32) {
@@ -893,7 +902,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define R_sc(f) (KARGS->sc.f)
 	extern __shared__ __align__(16) unsigned char smem[];
 	P *s_base = (P *)smem;
-	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
+	const int lane = (int)(threadIdx.x & 63u);
+	const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* (wave-uniform: a scalar) */
+	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + wave_in_block * WAVE_LDS_BYTES;
 	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(LdsBytes)(smem + LDS_ZERO_OFF);
 	const Lds<P> sb = (Lds<P>)(LdsBytes)smem; /* the base table again, as an LDS pointer */
 	__shared__ unsigned long long s_blockfree;
@@ -920,10 +931,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	 * decides whether three waves fit a SIMD). */
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	uint32_t slotv = slot;
-	/* the lane's number in its wave and in its block, taken from slotv where they are used (one v_and): a value derived from threadIdx.x at the
-	 * top of the kernel would be one more register across the loop - or, as it was, a spilled one fetched from scratch in front of every gather */
-#define lane ((int)(slotv & 63u))
-#define tid_in_block (slotv & (uint32_t)(LANE_BLOCK - 1))
 	/* The bases and sizes of the lane's scratch areas that the loop uses in (almost) every iteration, made OPAQUE scalar values: with more
 	 * wave-uniform values alive than scalar registers, the compiler drops kernel arguments and loads them again from the kernarg segment
 	 * where they are used - an s_load and a full wait on the scalar cache, five times per iteration in the first round-4 kernel
@@ -1588,7 +1595,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
 		/* heap entries stored (low half) and fetched (high half) by the wave: one LDS atomic per iteration (round 3 summed each of the two
 		 * per-lane counts over the wave with five ballots: fifty instructions of an issue-bound loop, profiles/r4_ab_steps.txt session 7) */
-		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[tid_in_block >> 6], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[wave_in_block], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		STAMP(5);
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);
@@ -1626,7 +1633,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 	}
 	if (lane == 0 && n_bkt) atomicAdd(&R_stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
-	if (lane == 0) { const unsigned long long sc_ = __hip_atomic_load((Lds<unsigned long long>)&s_cnt[threadIdx.x >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&R_stats[STAT_ENT_ST], sc_ & 0xFFFFFFFFull); atomicAdd(&R_stats[STAT_ENT_LD], sc_ >> 32); atomicAdd(&R_stats[STAT_REC_LD], (unsigned long long)n_rec); }
+	if (lane == 0) { const unsigned long long sc_ = __hip_atomic_load((Lds<unsigned long long>)&s_cnt[wave_in_block], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&R_stats[STAT_ENT_ST], sc_ & 0xFFFFFFFFull); atomicAdd(&R_stats[STAT_ENT_LD], sc_ >> 32); atomicAdd(&R_stats[STAT_REC_LD], (unsigned long long)n_rec); }
 	if (parked) atomicAdd(&R_stats[STAT_PARKED], 1ull);
 	if (lane == 0) {
 		atomicAdd(&R_stats[STAT_N], (unsigned long long)n_iter);            /* loop iterations of busy lanes */
@@ -1654,8 +1661,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 }
 
 #undef lbase
-#undef lane
-#undef tid_in_block
 #undef ERUNS_LO
 #undef ERUNS_HI
 #undef KARGS

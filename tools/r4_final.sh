@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-4 evidence session: everything under profiles/r4_* that is quoted for the FINAL kernels comes from this one session on one box.
+#   1. the whole GPU suite (with the GRCh37-size parity tests: they leave the C3 index in /tmp/bwb_bench for the steps below) + smoke()
+#   2. PMC traffic at C3 (tools/pmc_traffic.sh r4_c3) -> profiles/r4_c3_pmc.json, stamped with the hash of the kernel sources
+#   3. the bench line with the driver's arguments and all extras (cpu_baseline incl. interleaved, end_to_end, cli_end_to_end, rank_micro, n0)
+#   4. the same command under rocprofv3 --kernel-trace --stats (3 steps) -> r4_c3_kernel_stats.csv + the line it printed
+#   5. SQ counters of kl_search (tools/pmc_mem.sh, the SQ groups)
+#   6. config C5: PMC traffic + bench line; config C2: bench line
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4final; mkdir -p $O
+cd $R
+( time timeout 1500 python3 -m pytest tests -m gpu -x -q -s ) > $O/pytest.log 2>&1; echo "pytest exit $?"; grep -h "grch37\|passed\|failed\|skipped\|real" $O/pytest.log | tail -6
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
+cd /tmp && export TMPDIR=/tmp
+bash $R/tools/pmc_traffic.sh r4_c3 > $O/pmc_c3.log 2>&1; tail -3 $O/pmc_c3.log; cp $R/gpurun_out/r4_c3_pmc.json $R/profiles/r4_c3_pmc.json 2>/dev/null   # (so that the bench line below can quote it)
+( time timeout 2400 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_args.log 2> $O/bench_driver_args.err
+grep '^{"metric"' $O/bench_driver_args.log > $O/r4_bench_line_driver_args.json; tail -3 $O/bench_driver_args.err | cut -c1-200
+python3 $R/tools/ab_show.py c3_driver_args < $O/r4_bench_line_driver_args.json
+timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-extras > $O/r4_bench_line_under_rocprof.json 2> $O/trace.log
+cp $O/trace/run_kernel_stats.csv $O/r4_c3_kernel_stats.csv 2>/dev/null || cp $O/trace/*/run_kernel_stats.csv $O/r4_c3_kernel_stats.csv; head -4 $O/r4_c3_kernel_stats.csv | cut -c1-220
+cp $O/trace/run_kernel_trace.csv $O/r4_c3_kernel_trace.csv 2>/dev/null || cp $O/trace/*/run_kernel_trace.csv $O/r4_c3_kernel_trace.csv 2>/dev/null
+PMC_SETS="5 6 7" bash $R/tools/pmc_mem.sh 3100 10000000 2500000 3 > $O/pmc_mem_c3.log 2>&1; sed -n '/^ms /,$p' $O/pmc_mem_c3.log | head -30
+bash $R/tools/pmc_traffic.sh r4_c5 --config C5 > $O/pmc_c5.log 2>&1; tail -3 $O/pmc_c5.log; cp $R/gpurun_out/r4_c5_pmc.json $R/profiles/r4_c5_pmc.json 2>/dev/null
+timeout 2400 python3 $R/bench.py --config C5 --steps 10 --warmup 2 > $O/r4_bench_line_c5.json 2> $O/c5.err; python3 $R/tools/ab_show.py c5 < $O/r4_bench_line_c5.json
+timeout 1200 python3 $R/bench.py --config C2 --steps 20 --warmup 5 > $O/r4_bench_line_c2.json 2> $O/c2.err; python3 $R/tools/ab_show.py c2 < $O/r4_bench_line_c2.json
+ls $O
