@@ -82,14 +82,22 @@ struct LaneScratch {
  *   [12 KB, 12.5 KB) the exchange array of the gather
  * A rank is computed straight from the LDS rows, one 32-character sub-block at a time (four plane words in registers, not the
  * 2 x 32 words of both buckets as in round 2: the two kernels' register budgets are what allows three waves per SIMD). */
-#define NU_MAX 32
+#ifndef NU_MAX
+#define NU_MAX 32 /* compacted U rows per round (a multiple of 8) */
+#endif
 #define WAVE_STAGE_U4 (64 * 8 + NU_MAX * 8)
 #define WAVE_XCH_OFF (WAVE_STAGE_U4 * 16)
 #define WAVE_LDS_BYTES (WAVE_XCH_OFF + 512)
 /* block-level LDS in front of the waves' areas: the base table, then one all-zero 128-byte row that stands in for the bucket of a
  * position that needs none (-1, length-1, an idle lane): counts 0, no characters */
-/* (two base tables of BWB_BASE_ROWS rows: the exact one, then O_alphabet's view of it - load_base2 -; kl_calc_d only reads the first) */
-#define LDS_ZERO_OFF (2 * BWB_BASE_ROWS * 16 * 8)
+/* (after the base table one more row of it, load_base_q: O_alphabet's base C[j] - 1 of the codes 5, 9, 11, 13, the same in every superblock;
+ * kl_calc_d does not read it.  LDS is what three blocks per CU hang on: a whole second table - 1 280 bytes more - left room for two, at
+ * 13 % fewer reads/s, while the occupancy query still answered three: profiles/r4_ab_steps.txt sessions 9-10) */
+#ifdef BWB_BASE2_FULL
+#define LDS_ZERO_OFF ((BWB_BASE_ROWS + BWB_NSB_MAX) * 16 * 8)
+#else
+#define LDS_ZERO_OFF ((BWB_BASE_ROWS + 1) * 16 * 8)
+#endif
 #define LDS_WAVES_OFF (LDS_ZERO_OFF + 128)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
@@ -279,6 +287,7 @@ template <typename P> struct KidCtx {
 	int rot;
 	Lds<P> baseL, baseU;   /* base-table rows of the two positions */
 	bool qL, qU;           /* O_alphabet's view of the codes 5, 9, 11, 13 applies to this side: value = C[j] - [first char of the block == j] */
+	int dL, dU;            /* then: byte distance from the side's base row to the row of those codes' bases C[j] - 1 (load_base_q); else 0 */
 };
 /* child j = [vL(j) + 1, vU(j)] */
 template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &kc, Lds<P> s_base, int j, P &L, P &U) {
@@ -286,10 +295,16 @@ template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &k
 	const uint32_t x = (uint32_t)j << 2;
 	const uint32_t offL = ((((x & 0x30u) + ((uint32_t)kc.rot << 4)) & 0x70u) | (x & 0xCu));
 	const uint32_t rl = *(Lds<uint32_t>)((LdsBytes)kc.row + offL), ru = *(Lds<uint32_t>)((LdsBytes)kc.row + (offL ^ 0x40u));
-	/* (O_alphabet's view of the codes 5, 9, 11, 13 - value = C[j] - [first char of the block == j] - needs nothing here: side_finish left
-	 * rel = 1 - [first == j] and the side's base row is one of the second table, whose entries for these codes are C[j] - 1: load_base2) */
+	/* O_alphabet's view of the codes 5, 9, 11, 13 - value = C[j] - [first char of the block == j] -: side_finish left rel = 1 - [first == j],
+	 * and the base C[j] - 1 is read from the extra row instead of the side's own: three instructions per child for both sides (round 3:
+	 * two selects of the row, two of the -1 and the bit test) */
 	(void)s_base;
+#ifdef BWB_BASE2_FULL
 	const P bL = kc.baseL[j], bU = kc.baseU[j];
+#else
+	const int zq = (int)((QUIRK_CODES >> j) & 1u);
+	const P bL = ((Lds<P>)((LdsBytes)kc.baseL + __mul24(zq, kc.dL)))[j], bU = ((Lds<P>)((LdsBytes)kc.baseU + __mul24(zq, kc.dU)))[j];
+#endif
 	L = (P)(bL + (P)rl + 1); U = (P)(bU + (P)ru);
 }
 
@@ -313,7 +328,13 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	const int rot = (lane >> 1) & 7;
 	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
+#ifdef BWB_BASE2_FULL
 	kc.baseL = s_base + pi.rowL * 16 + (kc.qL ? BWB_BASE_ROWS * 16 : 0); kc.baseU = s_base + pi.rowU * 16 + (kc.qU ? BWB_BASE_ROWS * 16 : 0);
+	kc.dL = kc.dU = 0;
+#else
+	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
+	kc.dL = kc.qL ? (BWB_BASE_ROWS - pi.rowL) * 16 * (int)sizeof(P) : 0; kc.dU = kc.qU ? (BWB_BASE_ROWS - pi.rowU) * 16 * (int)sizeof(P) : 0;
+#endif
 	/* Both sides are independent one-pass ranks.  A lane's own row is source (counts 0-3, planes and mid counts 4-7: side L, and side U of
 	 * a pair in one bucket) and destination (relL -> 0-3, relU -> 4-7): what side L needs from the upper half goes to registers first,
 	 * then side U is finished (it still finds the counts in the lower half), then side L. */
@@ -925,7 +946,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	__shared__ unsigned int s_dstride[BWB_MAX_SLOTS];
 	if (threadIdx.x < BWB_MAX_SLOTS) { s_dbuf[threadIdx.x] = (unsigned long long)(uintptr_t)descs[threadIdx.x].b.dbuf; s_dstride[threadIdx.x] = descs[threadIdx.x].b.dstride; }
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
-	load_base2<P>(s_base, ix);
+	load_base_q<P>(s_base, ix);
 	/* The lane's scratch areas are addressed from its slot number where they are used: `slotv` is passed through an empty asm
 	 * statement in every iteration, so the compiler cannot keep six 64-bit pointers alive across the loop (registers are what
 	 * decides whether three waves fit a SIMD). */
@@ -1263,7 +1284,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(2);
 		HISTW(H_WAVE_NREQ_LE16, nreq <= 16 ? 1 : 0);
 		KidCtx<P> kc;
-		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
+		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false; kc.dL = kc.dU = 0;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: the record, LHeap::prefetch) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);
@@ -1594,8 +1615,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
 		/* heap entries stored (low half) and fetched (high half) by the wave: one LDS atomic per iteration (round 3 summed each of the two
-		 * per-lane counts over the wave with five ballots: fifty instructions of an issue-bound loop, profiles/r4_ab_steps.txt session 7) */
-		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[wave_in_block], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		 * per-lane counts over the wave with five ballots: fifty instructions of an issue-bound loop, profiles/r4_ab_steps.txt session 7).
+		 * The index goes through a vector register the compiler knows nothing about: with an address it can prove wave-uniform it replaces
+		 * the atomic by a 64-trip scalar loop over the lanes plus a vmcnt(0) wait - 21 % of the kernel's time in session 10. */
+		uint32_t wv = wave_in_block;
+		asm volatile("" : "+v"(wv));
+		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[wv], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		STAMP(5);
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);

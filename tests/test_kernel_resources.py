@@ -43,7 +43,8 @@ def test_search_kernel_register_budget(compiled):
     for k, ru in ks.items():
         assert ru["Occupancy"] >= 3 and ru["VGPRs"] <= 168, (k, ru)
     head = [v for k, v in ks.items() if "kl_searchImLb0ELb1E" in k][0]  # 64-bit positions (GRCh37 scale), 16-byte heap entries (-o <= 1), multi-genome
-    assert head["ScratchSize"] == 0 and head["VGPRs Spill"] == 0, head
+    # no vector register spilled and no scratch instruction in it (the frame itself may keep a few bytes that nothing touches)
+    assert head["VGPRs Spill"] == 0 and head["ScratchOps"] == 0 and head["ScratchSize"] <= 64, head
 
 
 def test_checker_sees_a_hazard():

@@ -60,6 +60,8 @@ def check_all(flags=()):
                 cur = None
                 continue
             kernels[cur].append(ln.strip())
+    for k, body in kernels.items():  # scratch instructions actually present (the frame may keep a few bytes no instruction uses)
+        remarks.setdefault(k, {})["ScratchOps"] = sum(1 for t in body if t.startswith("scratch_"))
     return {k: check_kernel(k, body) for k, body in kernels.items()}, remarks
 
 
@@ -135,7 +137,7 @@ def main():
     bad = 0
     for k, (n, errs) in res.items():
         ru = remarks.get(k, {})
-        print(f"{k}: {n} prefetch site(s), {'OK' if not errs else 'HAZARD'} | VGPRs {ru.get('VGPRs')} scratch {ru.get('ScratchSize')} B/lane, spills: {ru.get('SGPRs Spill')} SGPR, {ru.get('VGPRs Spill')} VGPR, {ru.get('Occupancy')} waves/SIMD")
+        print(f"{k}: {n} prefetch site(s), {'OK' if not errs else 'HAZARD'} | VGPRs {ru.get('VGPRs')} scratch {ru.get('ScratchSize')} B/lane ({ru.get('ScratchOps')} scratch instructions), spills: {ru.get('SGPRs Spill')} SGPR, {ru.get('VGPRs Spill')} VGPR, {ru.get('Occupancy')} waves/SIMD")
         for e in errs:
             print("   " + e)
         bad += len(errs)
