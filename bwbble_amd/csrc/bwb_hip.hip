@@ -362,16 +362,24 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 			if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
 			/* A slice's blocks must all be resident at once: a parked read only moves while its block runs, and a block that had to
 			 * wait for another one to leave would find the cursor exhausted and park again at once.  So never more blocks per CU than
-			 * the runtime says fit (registers, LDS). */
+			 * the runtime says fit (registers, LDS) - and never more than the LDS really holds: the runtime's answer was 3 for a block
+			 * size of which the hardware placed 2 (allocation in units of 1 280 bytes; profiles/r4_lds_probe.txt), which cost 13 % unnoticed. */
 			int occ = 0;
+			auto lds_fit = [&](const void *f) {
+				hipFuncAttributes fa;
+				if (hipFuncGetAttributes(&fa, f) != hipSuccess) return LANE_WAVES_PER_SIMD;
+				const size_t need = ((fa.sharedSizeBytes + lane_lds(c) + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE;
+				return (int)std::max<size_t>(1, LDS_CU_BYTES / need);
+			};
 			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true, true> : (const void *)kl_search<uint32_t, false, true>)
 			                          : (c->wide ? (const void *)kl_search<uint64_t, true, true> : (const void *)kl_search<uint64_t, false, true>); /* (the -S instantiations need no more) */
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
 				if (c->dbg && !s.ready) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU\n", occ, LANE_BLOCK);
-				c->bpc_search = std::min(c->bpc_search, occ);
+				c->bpc_search = std::min(c->bpc_search, std::min(occ, lds_fit(kf)));
+				if (c->dbg && !s.ready && lds_fit(kf) < occ) fprintf(stderr, "[bwb] kl_search: only %d block(s) per CU by LDS granules\n", lds_fit(kf));
 			}
 			const void *kd = c->pos32 ? (const void *)kl_calc_d<uint32_t> : (const void *)kl_calc_d<uint64_t>;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) c->bpc_calcd = std::min(c->bpc_calcd, occ);
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) c->bpc_calcd = std::min(c->bpc_calcd, std::min(occ, lds_fit(kd)));
 		}
 		/* (the scratch is sized for the larger grid: the two kernels share it) */
 		blocks = (uint32_t)(c->num_cu * std::max(LANE_WAVES_PER_SIMD, std::max(c->bpc_search, c->bpc_calcd))); lcap = 4096; acap = 256;

@@ -76,14 +76,16 @@ struct LaneScratch {
  *                    so that child j = [base[rowL][j] + relL[j] + 1, base[rowU][j] + relU[j]] (kid_get).  A visit needs the
  *                    interval of one or two children (a match, now and then a mismatch; deletions travel as one group entry),
  *                    so the 15 x 2 positions are no longer materialised: round 2 wrote 30 of them per visit.
- *   [8 KB, 12 KB)    NU_MAX rows: the bucket of position U of the lanes whose U falls into ANOTHER bucket, compacted (one pair
- *                    in six at GRCh37 scale: 11 of 64 lanes on average; when more than NU_MAX lanes of a wave need one, the rest
- *                    are fetched in a further round)
- *   [12 KB, 12.5 KB) the exchange array of the gather
+ *   [8 KB, 11 KB)    NU_MAX = 24 rows: the bucket of position U of the lanes whose U falls into ANOTHER bucket, compacted (22 % of the
+ *                    pairs at GRCh37 scale: 14 of 64 lanes on average; when more than NU_MAX lanes of a wave need one - the first
+ *                    positions of calculate_d, whose intervals span the whole index - the rest are fetched in a further round).
+ *                    Round 3 had 32 rows: one more load instruction in every iteration for rows that are almost never used
+ *                    (+1.6 % reads/s with 24, profiles/r4_ab_steps.txt session 11)
+ *   [11 KB, 11.5 KB) the exchange array of the gather
  * A rank is computed straight from the LDS rows, one 32-character sub-block at a time (four plane words in registers, not the
  * 2 x 32 words of both buckets as in round 2: the two kernels' register budgets are what allows three waves per SIMD). */
 #ifndef NU_MAX
-#define NU_MAX 32 /* compacted U rows per round (a multiple of 8) */
+#define NU_MAX 24 /* compacted U rows per round (a multiple of 8, at most 32: the exchange array holds four per column) */
 #endif
 #define WAVE_STAGE_U4 (64 * 8 + NU_MAX * 8)
 #define WAVE_XCH_OFF (WAVE_STAGE_U4 * 16)
@@ -99,6 +101,12 @@ struct LaneScratch {
 #define LDS_ZERO_OFF ((BWB_BASE_ROWS + 1) * 16 * 8)
 #endif
 #define LDS_WAVES_OFF (LDS_ZERO_OFF + 128)
+/* Three blocks per CU: the CU's 160 KB are handed out in units of 1 280 bytes (measured, bwbble_amd/tools_exp/lds_probe.hip ->
+ * profiles/r4_lds_probe.txt: 53 760 bytes per block give three resident blocks, 53 888 give two while the occupancy query still says
+ * three), static LDS of the kernel included (kl_search: 160 bytes). */
+#define LDS_CU_BYTES 163840
+#define LDS_GRANULE 1280
+static_assert(3 * (((LDS_WAVES_OFF + 4 * WAVE_LDS_BYTES + 256 + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE) <= LDS_CU_BYTES, "three blocks of four waves per CU no longer fit the LDS");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
 typedef __attribute__((address_space(3))) unsigned char *LdsBytes;

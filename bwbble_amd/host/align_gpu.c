@@ -60,6 +60,7 @@ typedef struct {
 	pipe_t *pp;
 	bwb_stats total;
 	double kernel_ms, t_ctx;
+	unsigned long long n_reads; /* reads of the chunks this worker took */
 } worker_t;
 
 /* The reader: chunk k+1 is parsed (record boundaries by one sequential scan, bases encoded by all cores: reads.c) while chunk k is on
@@ -189,6 +190,7 @@ static void *gpu_worker(void *arg) {
 			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
 		free(c->fq.seq); free(c->fq.len); free(c->carry); c->fq.seq = NULL; c->fq.len = NULL; c->carry = NULL; /* (staged by the library: the caller's buffers are free) */
 		in_slot[slot] = c;
+		w->n_reads += c->fq.n;
 		j++;
 		if (dbg) fprintf(stderr, "[bwb host] worker %d: chunk %zu (%u reads) submitted at +%.3f s\n", w->gpu, c->idx, c->fq.n, wall() - tq);
 	}
@@ -276,6 +278,10 @@ int align_reads_inexact_gpu_stream(bwt_t *BWT, const char *readsFname, aln_param
 		tot.heap_pops += ws[g].total.heap_pops; tot.n_alignments += ws[g].total.n_alignments; tot.n_overflow_reads += ws[g].total.n_overflow_reads;
 		if (ws[g].kernel_ms > kms) kms = ws[g].kernel_ms;
 		if (ws[g].t_ctx > tctx) tctx = ws[g].t_ctx;
+		if (n_gpus > 1) /* one line per worker: an uneven node (a slow link, a busy socket) shows here, not in the total */
+			printf("  GPU %d (device %d, NUMA node %d): reads %llu  kernel %.1f ms  index to HBM %.2f sec  launches %llu  parked reads %llu  re-run reads %llu\n", g, ws[g].device,
+			       bwb_hip_device_numa_node(ws[g].device), (unsigned long long)ws[g].n_reads, ws[g].kernel_ms, ws[g].t_ctx,
+			       (unsigned long long)ws[g].total.launches_search, (unsigned long long)ws[g].total.n_parked_reads, (unsigned long long)ws[g].total.n_overflow_reads);
 	}
 	const double dt = wall() - t0;
 	printf("GPUs: %d  reads: %llu  wall: %.3f sec (%.0f reads/s incl. index upload)  kernel: %.1f ms  index to HBM: %.2f sec  first chunk parsed after: %.2f sec  rank-block visits: %llu  hits: %llu  re-run reads: %llu\n",

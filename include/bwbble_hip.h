@@ -73,7 +73,7 @@ typedef struct {
 	uint64_t lane_iterations, wave_iterations; /* search loop iterations of busy lanes / of waves: their ratio = lanes busy of 64 */
 	uint64_t heap_entries_stored, heap_entries_loaded; /* heap entries the search kernel wrote to / read from its chunk pool (deletion children
 	                                                      travel as one group entry and a match child that is popped next stays in registers: fewer than pushes) */
-	uint64_t record_loads;       /* 8-byte per-position records {D, D_seed, base} the search kernel loaded */
+	uint64_t record_loads;       /* 16-byte records (four read positions each: D, D_seed, bases) the search kernel loaded */
 	double ms_calc_d;            /* HIP-event time of the calculate_d kernel(s) that have finished */
 	double ms_search;            /* HIP-event time of the inexact-search kernel(s) that have finished, all passes */
 	double ms_total;             /* batch_run: wall time of the call */
