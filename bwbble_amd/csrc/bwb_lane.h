@@ -208,10 +208,19 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	const uint32_t k = pi.ku - (uint32_t)first;
 	/* (the exchange array carries bucket << 3, the bucket's index in 16-byte slices - one add and one shift-add make the address; a bucket
 	 * number has 28 bits, NONE32 stays NONE32) */
-	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? NONE32 : pi.blkL << 3;
-	xch[64 + lane] = NONE32;
+#ifdef BWB_GATHER_BUF
+	/* Variant (A/B): the loads as structured-buffer loads - record = one 16-byte slice, index = (bucket << 3) + slice, 48-bit address arithmetic
+	 * in the address unit - through a descriptor whose record count ends below GATHER_IDLE: an owner that wants no bucket carries that index,
+	 * its lanes' loads are out of range and touch no memory.  No exec mask, no compare, no 64-bit address per load: three instructions a load
+	 * (index add, M0, load) instead of nine. */
+#define GATHER_IDLE 0xFFFFFFF0u
+#else
+#define GATHER_IDLE NONE32
+#endif
+	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? GATHER_IDLE : pi.blkL << 3;
+	xch[64 + lane] = GATHER_IDLE;
 	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU << 3;
-	u32x4 a0 = { NONE32, NONE32, NONE32, NONE32 }, a1 = a0;
+	u32x4 a0 = { GATHER_IDLE, GATHER_IDLE, GATHER_IDLE, GATHER_IDLE }, a1 = a0;
 	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
 	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
 	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the owners are in registers, and whatever was read from the rows before (the children of
@@ -223,6 +232,21 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	/* slice of instruction r = (p - ((8 r + sub) >> 1)) & 7 = (p - (sub >> 1) - 4 r) & 7: two values, for even and for odd r */
 	const uint32_t sl0 = (uint32_t)((p - (sub >> 1)) & 7), sl1 = sl0 ^ 4u;
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+#ifdef BWB_GATHER_BUF
+	const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)buckets, 16, (int)0xFFFFFFE0u, 0x00020000);
+	if (first == 0) {
+#pragma unroll
+		for (int r = 0; r < 8; r++)
+			__builtin_amdgcn_struct_ptr_buffer_load_lds(srd, (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, (int)(oL[r] + ((r & 1) ? sl1 : sl0)), 0, 0, 0, BWB_GATHER_AUX);
+	}
+	{
+		const uint32_t oUb[4] = { b0.x, b0.y, b0.z, b0.w };
+		const int nUrb = pi.nU - first;
+#pragma unroll
+		for (int r = 0; r < NU_MAX / 8; r++)
+			if (8 * r < nUrb) __builtin_amdgcn_struct_ptr_buffer_load_lds(srd, (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, (int)(oUb[r] + ((r & 1) ? sl1 : sl0)), 0, 0, 0, BWB_GATHER_AUX);
+	}
+#else
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		const uint32_t slice = (r & 1) ? sl1 : sl0;
@@ -234,6 +258,7 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 		const uint32_t slice = (r & 1) ? sl1 : sl0;
 		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
+#endif
 	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
 	                                       record, the heap entry a pop uncovered, the next list interval: all issued ahead of the gather) */
 	asm volatile("" ::: "memory");
