@@ -110,21 +110,15 @@ template <typename P> __device__ __forceinline__ void load_base(P *s_base, const
 	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) s_base[t] = (P)ix.base[t >> 4][t & 15];
 	__syncthreads();
 }
-/* the base table (exact counts: O(), bwt.c:348-372) and after it what O_alphabet's view (bwt.c:423-437) needs besides: the codes 5, 9, 11, 13 are
- * never counted there, their value inside any superblock is C[j] - 1 plus the 1 - [first char of the block == j] that the rank leaves
- * (bwb_lane.h: side_finish, kid_get) - one more row, holding C[j] - 1 for them.  (BWB_BASE2_FULL, an experiment: the superblock rows a second
- * time with those entries replaced - no address arithmetic per child, but 896 bytes more of LDS) */
-template <typename P> __device__ __forceinline__ void load_base_q(P *s_base, const DevIndex &ix) {
+/* the base table (exact counts: O(), bwt.c:348-372), then its superblock rows once more as O_alphabet sees them (bwt.c:423-437): the codes
+ * 5, 9, 11, 13 - never counted there - have C[j] - 1, to which the rank adds 1 - [first char of the block == j] (bwb_lane.h: side_finish);
+ * the special positions -1 and length-1 are exact in that view too: they use the first table's rows */
+template <typename P> __device__ __forceinline__ void load_base2(P *s_base, const DevIndex &ix) {
 	for (int t = threadIdx.x; t < BWB_BASE_ROWS * 16; t += BWB_BLOCK) {
 		const int row = t >> 4, j = t & 15;
 		const P v = (P)ix.base[row][j];
-		const bool qc = ((0x2A20u >> j) & 1u) != 0;
 		s_base[t] = v;
-#ifdef BWB_BASE2_FULL
-		if (row < BWB_NSB_MAX) s_base[BWB_BASE_ROWS * 16 + t] = qc ? (P)(ix.base[BWB_ROW_NEG][j] - 1) : v;
-#else
-		if (row == 0) s_base[BWB_BASE_ROWS * 16 + j] = qc ? (P)(ix.base[BWB_ROW_NEG][j] - 1) : (P)0;
-#endif
+		if (row < BWB_NSB_MAX) s_base[BWB_BASE_ROWS * 16 + t] = ((0x2A20u >> j) & 1u) ? (P)(ix.base[BWB_ROW_NEG][j] - 1) : v;
 	}
 	__syncthreads();
 }

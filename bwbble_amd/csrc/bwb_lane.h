@@ -92,14 +92,10 @@ struct LaneScratch {
 #define WAVE_LDS_BYTES (WAVE_XCH_OFF + 512)
 /* block-level LDS in front of the waves' areas: the base table, then one all-zero 128-byte row that stands in for the bucket of a
  * position that needs none (-1, length-1, an idle lane): counts 0, no characters */
-/* (after the base table one more row of it, load_base_q: O_alphabet's base C[j] - 1 of the codes 5, 9, 11, 13, the same in every superblock;
- * kl_calc_d does not read it.  LDS is what three blocks per CU hang on: a whole second table - 1 280 bytes more - left room for two, at
- * 13 % fewer reads/s, while the occupancy query still answered three: profiles/r4_ab_steps.txt sessions 9-10) */
-#ifdef BWB_BASE2_FULL
+/* (after the base table its superblock rows a second time, as O_alphabet sees them - load_base2 -; kl_calc_d only reads the first.  LDS is
+ * what three blocks per CU hang on: this second table, when the waves' areas still had 32 U rows, left room for two blocks only - 13 %
+ * fewer reads/s, while the occupancy query still answered three: profiles/r4_ab_steps.txt sessions 9-12) */
 #define LDS_ZERO_OFF ((BWB_BASE_ROWS + BWB_NSB_MAX) * 16 * 8)
-#else
-#define LDS_ZERO_OFF ((BWB_BASE_ROWS + 1) * 16 * 8)
-#endif
 #define LDS_WAVES_OFF (LDS_ZERO_OFF + 128)
 /* Three blocks per CU: the CU's 160 KB are handed out in units of 1 280 bytes (measured, bwbble_amd/tools_exp/lds_probe.hip ->
  * profiles/r4_lds_probe.txt: 53 760 bytes per block give three resident blocks, 53 888 give two while the occupancy query still says
@@ -208,19 +204,10 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	const uint32_t k = pi.ku - (uint32_t)first;
 	/* (the exchange array carries bucket << 3, the bucket's index in 16-byte slices - one add and one shift-add make the address; a bucket
 	 * number has 28 bits, NONE32 stays NONE32) */
-#ifdef BWB_GATHER_BUF
-	/* Variant (A/B): the loads as structured-buffer loads - record = one 16-byte slice, index = (bucket << 3) + slice, 48-bit address arithmetic
-	 * in the address unit - through a descriptor whose record count ends below GATHER_IDLE: an owner that wants no bucket carries that index,
-	 * its lanes' loads are out of range and touch no memory.  No exec mask, no compare, no 64-bit address per load: three instructions a load
-	 * (index add, M0, load) instead of nine. */
-#define GATHER_IDLE 0xFFFFFFF0u
-#else
-#define GATHER_IDLE NONE32
-#endif
-	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? GATHER_IDLE : pi.blkL << 3;
-	xch[64 + lane] = GATHER_IDLE;
+	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? NONE32 : pi.blkL << 3;
+	xch[64 + lane] = NONE32;
 	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU << 3;
-	u32x4 a0 = { GATHER_IDLE, GATHER_IDLE, GATHER_IDLE, GATHER_IDLE }, a1 = a0;
+	u32x4 a0 = { NONE32, NONE32, NONE32, NONE32 }, a1 = a0;
 	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
 	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
 	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the owners are in registers, and whatever was read from the rows before (the children of
@@ -232,21 +219,6 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	/* slice of instruction r = (p - ((8 r + sub) >> 1)) & 7 = (p - (sub >> 1) - 4 r) & 7: two values, for even and for odd r */
 	const uint32_t sl0 = (uint32_t)((p - (sub >> 1)) & 7), sl1 = sl0 ^ 4u;
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-#ifdef BWB_GATHER_BUF
-	const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc((void *)buckets, 16, (int)0xFFFFFFE0u, 0x00020000);
-	if (first == 0) {
-#pragma unroll
-		for (int r = 0; r < 8; r++)
-			__builtin_amdgcn_struct_ptr_buffer_load_lds(srd, (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, (int)(oL[r] + ((r & 1) ? sl1 : sl0)), 0, 0, 0, BWB_GATHER_AUX);
-	}
-	{
-		const uint32_t oUb[4] = { b0.x, b0.y, b0.z, b0.w };
-		const int nUrb = pi.nU - first;
-#pragma unroll
-		for (int r = 0; r < NU_MAX / 8; r++)
-			if (8 * r < nUrb) __builtin_amdgcn_struct_ptr_buffer_load_lds(srd, (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, (int)(oUb[r] + ((r & 1) ? sl1 : sl0)), 0, 0, 0, BWB_GATHER_AUX);
-	}
-#else
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
 		const uint32_t slice = (r & 1) ? sl1 : sl0;
@@ -258,7 +230,9 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 		const uint32_t slice = (r & 1) ? sl1 : sl0;
 		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
-#endif
+	/* (Tried, session 12: the loads as structured-buffer loads - record = slice, idle owners out of range, no exec mask, three instructions
+	 * a load instead of nine.  Correct on every test index and wrong at GRCh37 size: without swizzling the range check works on bytes,
+	 * 32 bits of them, and the table has 13.7 GB.) */
 	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
 	                                       record, the heap entry a pop uncovered, the next list interval: all issued ahead of the gather) */
 	asm volatile("" ::: "memory");
@@ -320,7 +294,6 @@ template <typename P> struct KidCtx {
 	int rot;
 	Lds<P> baseL, baseU;   /* base-table rows of the two positions */
 	bool qL, qU;           /* O_alphabet's view of the codes 5, 9, 11, 13 applies to this side: value = C[j] - [first char of the block == j] */
-	int dL, dU;            /* then: byte distance from the side's base row to the row of those codes' bases C[j] - 1 (load_base_q); else 0 */
 };
 /* child j = [vL(j) + 1, vU(j)] */
 template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &kc, Lds<P> s_base, int j, P &L, P &U) {
@@ -328,16 +301,11 @@ template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &k
 	const uint32_t x = (uint32_t)j << 2;
 	const uint32_t offL = ((((x & 0x30u) + ((uint32_t)kc.rot << 4)) & 0x70u) | (x & 0xCu));
 	const uint32_t rl = *(Lds<uint32_t>)((LdsBytes)kc.row + offL), ru = *(Lds<uint32_t>)((LdsBytes)kc.row + (offL ^ 0x40u));
-	/* O_alphabet's view of the codes 5, 9, 11, 13 - value = C[j] - [first char of the block == j] -: side_finish left rel = 1 - [first == j],
-	 * and the base C[j] - 1 is read from the extra row instead of the side's own: three instructions per child for both sides (round 3:
-	 * two selects of the row, two of the -1 and the bit test) */
+	/* (O_alphabet's view of the codes 5, 9, 11, 13 - value = C[j] - [first char of the block == j] - needs nothing here: side_finish left
+	 * rel = 1 - [first == j] and the side's base row is one of the second table, whose entries for these codes are C[j] - 1: load_base2.
+	 * Round 3 selected the row and the -1 per child: ten instructions; one extra row and a multiply-add: three, and 2 % slower than this) */
 	(void)s_base;
-#ifdef BWB_BASE2_FULL
 	const P bL = kc.baseL[j], bU = kc.baseU[j];
-#else
-	const int zq = (int)((QUIRK_CODES >> j) & 1u);
-	const P bL = ((Lds<P>)((LdsBytes)kc.baseL + __mul24(zq, kc.dL)))[j], bU = ((Lds<P>)((LdsBytes)kc.baseU + __mul24(zq, kc.dU)))[j];
-#endif
 	L = (P)(bL + (P)rl + 1); U = (P)(bU + (P)ru);
 }
 
@@ -361,13 +329,8 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	const int rot = (lane >> 1) & 7;
 	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
-#ifdef BWB_BASE2_FULL
+	/* (qL / qU imply a superblock row, 0 .. BWB_NSB_MAX - 1: the second table has just those) */
 	kc.baseL = s_base + pi.rowL * 16 + (kc.qL ? BWB_BASE_ROWS * 16 : 0); kc.baseU = s_base + pi.rowU * 16 + (kc.qU ? BWB_BASE_ROWS * 16 : 0);
-	kc.dL = kc.dU = 0;
-#else
-	kc.baseL = s_base + pi.rowL * 16; kc.baseU = s_base + pi.rowU * 16;
-	kc.dL = kc.qL ? (BWB_BASE_ROWS - pi.rowL) * 16 * (int)sizeof(P) : 0; kc.dU = kc.qU ? (BWB_BASE_ROWS - pi.rowU) * 16 * (int)sizeof(P) : 0;
-#endif
 	/* Both sides are independent one-pass ranks.  A lane's own row is source (counts 0-3, planes and mid counts 4-7: side L, and side U of
 	 * a pair in one bucket) and destination (relL -> 0-3, relU -> 4-7): what side L needs from the upper half goes to registers first,
 	 * then side U is finished (it still finds the counts in the lower half), then side L. */
@@ -979,7 +942,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	__shared__ unsigned int s_dstride[BWB_MAX_SLOTS];
 	if (threadIdx.x < BWB_MAX_SLOTS) { s_dbuf[threadIdx.x] = (unsigned long long)(uintptr_t)descs[threadIdx.x].b.dbuf; s_dstride[threadIdx.x] = descs[threadIdx.x].b.dstride; }
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
-	load_base_q<P>(s_base, ix);
+	load_base2<P>(s_base, ix);
 	/* The lane's scratch areas are addressed from its slot number where they are used: `slotv` is passed through an empty asm
 	 * statement in every iteration, so the compiler cannot keep six 64-bit pointers alive across the loop (registers are what
 	 * decides whether three waves fit a SIMD). */
@@ -1317,7 +1280,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(2);
 		HISTW(H_WAVE_NREQ_LE16, nreq <= 16 ? 1 : 0);
 		KidCtx<P> kc;
-		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false; kc.dL = kc.dU = 0;
+		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: the record, LHeap::prefetch) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);

@@ -62,6 +62,9 @@ def check_all(flags=()):
             kernels[cur].append(ln.strip())
     for k, body in kernels.items():  # scratch instructions actually present (the frame may keep a few bytes no instruction uses)
         remarks.setdefault(k, {})["ScratchOps"] = sum(1 for t in body if t.startswith("scratch_"))
+        # wave reductions the compiler put in place of atomics with a provably uniform address (a scalar loop over the lanes each): fine in the
+        # rare paths, 21 % of the kernel's time when one landed in the loop (profiles/r4_ab_steps.txt, session 10)
+        remarks[k]["ComputeLoops"] = sum(1 for t in body if "%ComputeLoop" in t)
     return {k: check_kernel(k, body) for k, body in kernels.items()}, remarks
 
 

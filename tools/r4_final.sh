@@ -2,7 +2,8 @@
 # Round-4 evidence session: everything under profiles/r4_* that is quoted for the FINAL kernels comes from this one session on one box.
 #   1. the whole GPU suite (with the GRCh37-size parity tests: they leave the C3 index in /tmp/bwb_bench for the steps below) + smoke()
 #   2. PMC traffic at C3 (tools/pmc_traffic.sh r4_c3) -> profiles/r4_c3_pmc.json, stamped with the hash of the kernel sources
-#   3. the bench line with the driver's arguments and all extras (cpu_baseline incl. interleaved, end_to_end, cli_end_to_end, rank_micro, n0)
+#   3. the bench line with the driver's arguments and all extras (cpu_baseline incl. interleaved, end_to_end, cli_end_to_end, rank_micro, n0);
+#      the CLI once more with its .aln checked in two places (tools/cli_check.py)
 #   4. the same command under rocprofv3 --kernel-trace --stats (3 steps) -> r4_c3_kernel_stats.csv + the line it printed
 #   5. SQ counters of kl_search (tools/pmc_mem.sh, the SQ groups)
 #   6. config C5: PMC traffic + bench line; config C2: bench line
@@ -16,6 +17,7 @@ bash $R/tools/pmc_traffic.sh r4_c3 > $O/pmc_c3.log 2>&1; tail -3 $O/pmc_c3.log; 
 ( time timeout 2400 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_args.log 2> $O/bench_driver_args.err
 grep '^{"metric"' $O/bench_driver_args.log > $O/r4_bench_line_driver_args.json; tail -3 $O/bench_driver_args.err | cut -c1-200
 python3 $R/tools/ab_show.py c3_driver_args < $O/r4_bench_line_driver_args.json
+( time timeout 900 python3 $R/tools/cli_check.py /tmp/bwb_bench/genome_3100000000.fa /tmp/bwb_bench/reads_3100000000_10000000_100_i0.1_r0.fq 5000 -n 3 ) > $O/r4_cli_c3.txt 2>&1; tail -6 $O/r4_cli_c3.txt
 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-extras > $O/r4_bench_line_under_rocprof.json 2> $O/trace.log
 cp $O/trace/run_kernel_stats.csv $O/r4_c3_kernel_stats.csv 2>/dev/null || cp $O/trace/*/run_kernel_stats.csv $O/r4_c3_kernel_stats.csv; head -4 $O/r4_c3_kernel_stats.csv | cut -c1-220
 cp $O/trace/run_kernel_trace.csv $O/r4_c3_kernel_trace.csv 2>/dev/null || cp $O/trace/*/run_kernel_trace.csv $O/r4_c3_kernel_trace.csv 2>/dev/null
