@@ -4,8 +4,10 @@
  * alignment loop handed to libbwbble_hip.so through include/bwbble_hip.h.
  *
  * Names follow the reference (mg-aligner/{bwt.h,io.h,align.h,inexact_match.h}) so that the seam is
- * obvious: align_reads_inexact_gpu() has the signature of align_reads_inexact_parallel()
- * (inexact_match.h:40) and is selected next to it in align_reads() (align.c:72-76).
+ * obvious: align_reads_inexact_gpu_stream() stands where align_reads_inexact_parallel() (inexact_match.h:40) is
+ * selected in align_reads() (align.c:72-76); it takes the FASTQ's NAME instead of the loaded reads_t - the file is streamed
+ * through a reader thread while the index is still on its way to the GPU (align_gpu.c).  The drop-in binding with the
+ * reference's exact signature, for a maintainer who keeps the reference's host code, is integration/align_gpu.c.
  */
 #ifndef BWB_HOST_H
 #define BWB_HOST_H
