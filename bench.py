@@ -457,10 +457,19 @@ def cpu_baseline(a, fa, fq, flags, off, alns, bw):
         # other socket's threads walk it over the inter-socket link.  The same binary under `numactl --interleave=all` (when the box
         # has it) says what the reference does once its pages are spread - reported next to the plain run, not instead of it.
         import shutil
-        if shutil.which("numactl") and not a.cpu_sample:
+        il_helper = os.path.join(ROOT, "oracle", "interleave_exec")  # (the same policy through the raw system call: the GPU boxes have no numactl)
+        il_cmd = ["numactl", "--interleave=all"] if shutil.which("numactl") else ([il_helper] if os.path.exists(il_helper) else None)
+        if il_cmd and not a.cpu_sample:
+            try:
+                nodes_now = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+            except OSError:
+                nodes_now = 1
+            if nodes_now < 2:
+                il_cmd = None
+        if il_cmd and not a.cpu_sample:
             def t_run_il(path, out, t):
                 t0 = time.perf_counter()
-                subprocess.run(["numactl", "--interleave=all", ref_bin, "align"] + flags + ["-t", str(t), fa, path, out], check=True, stdout=subprocess.DEVNULL)
+                subprocess.run(il_cmd + [ref_bin, "align"] + flags + ["-t", str(t), fa, path, out], check=True, stdout=subprocess.DEVNULL)
                 return time.perf_counter() - t0
             il = []
             for t in ts:
@@ -474,9 +483,9 @@ def cpu_baseline(a, fa, fq, flags, off, alns, bw):
                            "reads_per_s_per_thread": round(n_il / sec / t, 2)})
             bi = max(il, key=lambda r: r["reads_per_s"])
             res["interleaved"] = {"value": bi["reads_per_s"], "threads": bi["threads"], "reads_per_s_per_thread": bi["reads_per_s_per_thread"],
-                                  "sweep": il, "command": "numactl --interleave=all oracle/_ref/bwbble align ..."}
+                                  "sweep": il, "command": " ".join(os.path.basename(x) for x in il_cmd) + " oracle/_ref/bwbble align ..."}
         else:
-            res["interleaved"] = None if a.cpu_sample else "numactl not installed on this box"
+            res["interleaved"] = None if a.cpu_sample else "one NUMA node, or neither numactl nor oracle/interleave_exec on this box"
         try:
             nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
         except OSError:
