@@ -28,10 +28,11 @@ def test_config_defaults(monkeypatch):
 
 
 def test_stored_pmc_profile_is_quoted_only_for_the_kernels_it_was_measured_on(monkeypatch):
-    """bench.py quotes profiles/r3_*_pmc.json as roofline.traffic only when its hash equals that of bwbble_amd/csrc/*; on other
-    sources it says so instead (a kernel edit makes the stored traffic figure disappear from the line, not go stale)."""
+    """bench.py quotes the newest profiles/r<N>_c3_pmc.json as roofline.traffic only when its hash equals that of bwbble_amd/csrc/*; on
+    other sources it says so instead (a kernel edit makes the stored traffic figure disappear from the line, not go stale)."""
     import bench
-    pj = json.load(open(os.path.join(ROOT, "profiles", "r3_c3_pmc.json")))
+    import glob
+    pj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_c3_pmc.json")))[-1]))
     assert pj["kl_search"]["hbm_bytes_per_step"] > pj["kl_search"]["device_bytes_per_step"] > 0
     cal = pj["calibration_7GiB_table"]
     assert abs(cal["k_coop"]["RDREQ_per_request"] - 1.0) < 0.01 and abs(cal["k_meta8"]["RDREQ_per_request"] - 1.0) < 0.01
