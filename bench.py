@@ -472,7 +472,7 @@ def cpu_baseline(a, fa, fq, flags, off, alns, bw):
                 subprocess.run(il_cmd + [ref_bin, "align"] + flags + ["-t", str(t), fa, path, out], check=True, stdout=subprocess.DEVNULL)
                 return time.perf_counter() - t0
             il = []
-            for t in ts:
+            for t in [best_t]:  # (the plain sweep's best -t, on the same sample as `final`: the interleaved sweeps of round 4 had the same best -t)
                 n_il = min(200 * t if t == best_t else 64 * t, a.reads)
                 sfq_il = fq + f".sample{n_il}"
                 if not os.path.exists(sfq_il):
