@@ -311,7 +311,8 @@ def measured_traffic(a, B, dom_name, dom):
 def stored_n1_value(a):
     """the 1-GPU bench line of the same workload kept under profiles/ (for the informational efficiency figure of a multi-GPU run)"""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_bench_line*.json")), reverse=True):
+    # (newest round first; within a round the line taken with the driver's arguments before the short profiling runs)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_bench_line*.json")), key=lambda f: (int("".join(ch for ch in os.path.basename(f).split("_")[0] if ch.isdigit()) or 0), "driver_args" in f, f), reverse=True):
         try:
             j = json.loads(open(f).read().strip().splitlines()[-1])
         except Exception:

@@ -362,3 +362,19 @@ def test_aln_reader_and_writer_round_trip(built, golden, tmp_path, aln):
         for ea, eb in zip(ra, rb):
             assert {k: v for k, v in ea.items() if k != "states"} == {k: v for k, v in eb.items() if k != "states"}
             assert ea["states"] == eb["states"][::-1]
+
+
+def test_interleave_helper_runs_the_command_or_says_why_not():
+    """oracle/interleave_exec (bench.py's cpu_baseline: the reference under an interleaving NUMA policy on boxes without numactl):
+    on a one-node machine it refuses with exit code 125 and runs nothing; with several nodes it execs the command."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "interleave_exec")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), exe], check=True)
+    nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]) if os.path.isdir("/sys/devices/system/node") else 0
+    r = subprocess.run([exe, "sh", "-c", "echo ran"], capture_output=True, text=True)
+    if nodes >= 2 and r.returncode != 125:  # (125 also when the container forbids set_mempolicy)
+        assert r.returncode == 0 and r.stdout.strip() == "ran"
+    else:
+        assert r.returncode == 125 and "ran" not in r.stdout
+    assert subprocess.run([exe], capture_output=True).returncode == 2
