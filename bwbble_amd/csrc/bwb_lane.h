@@ -152,50 +152,6 @@ __device__ __forceinline__ void pair_setup(P last_row, bool need, P pL, P pU, in
  * the 8 owners of its column with 128-bit reads; round 2 used 16 ds_bpermute).
  * Round `first` == 0 fetches the L rows and the U rows of the compacted owners [0, NU_MAX); a later round (first = NU_MAX, ...)
  * only the U rows of the owners [first, first + NU_MAX).  Called by EVERY lane of the wave. */
-#ifdef BWB_GATHER2
-/* Variant (A/B): the same gather with fewer instructions per load (12 loads per iteration): (1) an owner that wants no bucket (an idle lane, a
- * compacted U slot beyond the wave's count) loads bucket 0 instead of being masked off - its row is never read (the zero row stands in) - so
- * no load needs an exec mask, and the U instructions beyond the wave's count are skipped by a scalar branch; (2) the exchange array carries
- * bucket << 3, the bucket's index in 16-byte slices, so that the address is one add and one shift-add; (3) the LDS destination (M0) is built
- * from a scalar copy of the wave's LDS base instead of a vector add and a readfirstlane per load. */
-template <typename P>
-__device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, const PairInfo<P> &pi, int first, Lds<u32x4> stage, int lane) {
-	const int sub = lane >> 3, p = lane & 7;
-	Lds<uint32_t> xch = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF);
-	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU_MAX;
-	const uint32_t k = pi.ku - (uint32_t)first;
-	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? 0u : pi.blkL << 3;
-	xch[64 + lane] = 0u;
-	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU << 3;
-	u32x4 a0 = { 0u, 0u, 0u, 0u }, a1 = a0;
-	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
-	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
-	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */
-	uint32_t sv = (uint32_t)(uintptr_t)stage;
-	asm volatile("" : "+v"(sv)); /* (not loop-invariant for the compiler: a scalar kept across the loop would be one more spilled SGPR) */
-	const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
-	/* slice of instruction r = (p - ((8 r + sub) >> 1)) & 7 = (p - (sub >> 1) - 4 r) & 7: two values, for even and for odd r */
-	const uint32_t sl0 = (uint32_t)((p - (sub >> 1)) & 7), sl1 = sl0 ^ 4u;
-	const int nUr = pi.nU - first; /* (wave-uniform) U owners of this round: those beyond NU_MAX wait for the next */
-	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-	if (first == 0) {
-#pragma unroll
-		for (int r = 0; r < 8; r++) {
-			const uint32_t slice = (r & 1) ? sl1 : sl0;
-			__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
-		}
-	}
-	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
-#pragma unroll
-	for (int r = 0; r < NU_MAX / 8; r++) {
-		const uint32_t slice = (r & 1) ? sl1 : sl0;
-		if (8 * r < nUr) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
-	}
-	__builtin_amdgcn_s_waitcnt(0x0F70);
-	asm volatile("" ::: "memory");
-	__builtin_amdgcn_wave_barrier();
-}
-#else
 template <typename P>
 __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, const PairInfo<P> &pi, int first, Lds<u32x4> stage, int lane) {
 	const int sub = lane >> 3, p = lane & 7;
@@ -238,7 +194,6 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	asm volatile("" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
 }
-#endif
 
 /* Rank from a 64-character bucket (bwb_device.h): acc[j] = #j among the first n (0..32) characters of the sub-block whose planes are p,
  * j = 1..15: ONE masked pass. */
@@ -1013,6 +968,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	uint32_t r_vis_s = 0, r_vis_a = 0, r_pop = 0, r_push = 0; /* per read; committed (one atomic each, straight to the statistics) only when the read completes */
 	uint32_t n_iter = 0, w_iter = 0;                          /* iterations of this lane / of this wave in this launch */
 	uint32_t n_bkt = 0, n_rec = 0; /* wave-uniform: buckets fetched, records loaded (heap entries stored / fetched: s_cnt) */
+	uint32_t acc_st = 0, acc_ld = 0; /* per lane, for the whole launch: heap entries stored / fetched (summed over the wave once, at the end) */
 	bool parked = false;
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -1610,13 +1566,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		HIST(H_TOP_RELOAD, ld_cnt != 0);
 		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
 		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
-		/* heap entries stored (low half) and fetched (high half) by the wave: one LDS atomic per iteration (round 3 summed each of the two
-		 * per-lane counts over the wave with five ballots: fifty instructions of an issue-bound loop, profiles/r4_ab_steps.txt session 7).
-		 * The index goes through a vector register the compiler knows nothing about: with an address it can prove wave-uniform it replaces
-		 * the atomic by a 64-trip scalar loop over the lanes plus a vmcnt(0) wait - 21 % of the kernel's time in session 10. */
-		uint32_t wv = wave_in_block;
-		asm volatile("" : "+v"(wv));
-		__hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[wv], (unsigned long long)st_cnt | ((unsigned long long)ld_cnt << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		/* heap entries stored / fetched: two per-lane accumulators, summed over the wave ONCE per launch (after the loop: one LDS atomic whose
+		 * index goes through a vector register the compiler knows nothing about - with an address it can prove wave-uniform it replaces the
+		 * atomic by a 64-trip scalar loop).  Round 4 did that atomic in every iteration: 64 lanes on one LDS address were the bank conflicts
+		 * of profiles/r4_c3_pmc_sq_final.txt; +0.7 % reads/s without them (profiles/r4_ab_steps.txt session 14). */
+		acc_st += st_cnt; acc_ld += ld_cnt;
 		STAMP(5);
 		if (ovf) finish = true;
 		HIST(H_FINISH, finish);
@@ -1654,6 +1608,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		}
 	}
 	if (lane == 0 && n_bkt) atomicAdd(&R_stats[STAT_BKT_SEARCH], (unsigned long long)n_bkt);
+	{ uint32_t wv = wave_in_block; asm volatile("" : "+v"(wv));
+	  __hip_atomic_fetch_add((Lds<unsigned long long>)&s_cnt[wv], (unsigned long long)acc_st | ((unsigned long long)acc_ld << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 	if (lane == 0) { const unsigned long long sc_ = __hip_atomic_load((Lds<unsigned long long>)&s_cnt[wave_in_block], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicAdd(&R_stats[STAT_ENT_ST], sc_ & 0xFFFFFFFFull); atomicAdd(&R_stats[STAT_ENT_LD], sc_ >> 32); atomicAdd(&R_stats[STAT_REC_LD], (unsigned long long)n_rec); }
 	if (parked) atomicAdd(&R_stats[STAT_PARKED], 1ull);
 	if (lane == 0) {
