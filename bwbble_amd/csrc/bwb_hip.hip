@@ -940,6 +940,16 @@ static int read_device_stats(bwb_hip_ctx *c) {
 		fprintf(stderr, "\n");
 	}
 #endif
+#ifdef BWB_BBPROF
+	if (const char *bo = getenv("BWB_BBPROF_OUT")) { /* tools/bbprof.py: the basic-block counters of the instrumented kernels, one JSON line per call */
+		if (FILE *f = fopen(bo, "a")) {
+			fprintf(f, "{\"wave_iterations_search\": %llu, \"wave_iterations_calc_d\": %llu, \"lane_iterations_search\": %llu, \"counters\": [", st[STAT_WAVE_ITERS], st[STAT_WAVE_ITERS_CALCD], st[STAT_N]);
+			for (int k = 0; k < 2048; k++) fprintf(f, "%s%llu", k ? "," : "", st[STAT_BBPROF + k]);
+			fprintf(f, "]}\n");
+			fclose(f);
+		}
+	}
+#endif
 #ifdef BWB_STAMPS
 	if (st[STAT_STAMPS + 3]) {
 		double tot = 0; for (int k = 0; k < 16; k++) tot += (double)st[STAT_STAMPS + k];

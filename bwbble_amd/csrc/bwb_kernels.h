@@ -72,7 +72,12 @@ struct Work {
 enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N, STAT_N_MAX, STAT_VIS_CALCD,
        STAT_BKT_SEARCH /* 128-byte buckets fetched by kl_search */, STAT_BKT_CALCD, STAT_PARKED /* reads parked at the end of a slice */,
        STAT_ENT_ST /* heap entries kl_search stored */, STAT_ENT_LD /* ... loaded */, STAT_REC_LD /* per-position records it loaded */,
-       STAT_WAVE_ITERS = 16, STAT_STAMPS = 24, STAT_HIST = 40 /* BWB_HIST diagnostic build */, STAT_WORDS = 104 };
+       STAT_WAVE_ITERS = 16, STAT_WAVE_ITERS_CALCD = 17, STAT_STAMPS = 24, STAT_HIST = 40 /* BWB_HIST diagnostic build */, STAT_BBPROF = 104 /* tools/bbprof.py: one 64-bit counter per basic block */,
+#ifdef BWB_BBPROF
+       STAT_WORDS = 104 + 2048 };
+#else
+       STAT_WORDS = 104 };
+#endif
 
 template <typename P> struct Intv { P L, U; };
 
