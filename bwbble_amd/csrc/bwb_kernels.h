@@ -95,9 +95,12 @@ template <typename P> struct Intv { P L, U; };
 #define REC_BYTES 16
 __host__ __device__ __forceinline__ uint32_t rec_count(uint32_t len) { return (len >> 2) + 1u; }
 /* the byte D[k] (arr = 0) or DS[k] (arr = 8), k >= -2: in record (k + 2) >> 2, and again in the record before it when it is one of a record's first two */
-__device__ __forceinline__ void rec_put(uint8_t *recs, int arr, int k, uint32_t v) {
+/* (nrec = rec_count(len): the byte of the read's LAST position k = len - 1 has no record of its own when len % 4 == 3 - no entry sits beyond
+ * position len - and is only written into the record before, where the entries at position len look for it; round 4 wrote it one record past
+ * the read's records, into the per-read tail that holds calculate_d's work counter: ADVICE r4) */
+__device__ __forceinline__ void rec_put(uint8_t *recs, uint32_t nrec, int arr, int k, uint32_t v) {
 	const int m = (k + 2) >> 2, t = (k + 2) & 3;
-	recs[REC_BYTES * m + arr + t] = (uint8_t)v;
+	if ((uint32_t)m < nrec) recs[REC_BYTES * m + arr + t] = (uint8_t)v;
 	if (t < 2 && m > 0) recs[REC_BYTES * (m - 1) + arr + 4 + t] = (uint8_t)v;
 }
 __device__ __forceinline__ uint32_t rec_get(const uint8_t *recs, int arr, int k) { return recs[REC_BYTES * ((k + 2) >> 2) + arr + ((k + 2) & 3)]; }
@@ -273,7 +276,7 @@ __global__ void k_dseed_inherit(Batch b, const uint32_t *src, uint32_t n) {
 	uint8_t *rr = b.dbuf + (size_t)r * b.dstride;
 	const uint8_t *rq = b.dbuf + (size_t)q * b.dstride;
 	/* DS of read r at position k (of r) = DS of read q at position k + len_q - len_r (of q): the same seed index */
-	for (int k = -2; k < lr; k++) rec_put(rr, 8, k, rec_get(rq, 8, k + lq - lr));
+	for (int k = -2; k < lr; k++) rec_put(rr, rec_count((uint32_t)lr), 8, k, rec_get(rq, 8, k + lq - lr));
 }
 
 /* SA[row] by the invPsi walk (bwt.c:311-329): one octet per row */

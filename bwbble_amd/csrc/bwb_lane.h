@@ -227,14 +227,26 @@ __device__ __forceinline__ void side_read(Lds<u32x4> row, int rot, int off, Side
  * left them in the count-slice order, whose address arithmetic cost more than the rank's adds); `quirk`: O_alphabet's view of 5, 9, 11, 13.
  * Every count slice is read before the first result is written: the row is source and destination. */
 __device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const SideBits &sb, bool quirk, Lds<u32x4> own, int rot, int dst0) {
-	uint32_t acc[16];
-	sub_pops16(sb.planes, sb.n, acc);
+	/* acc[c] = count slice + popcount in ONE v_bcnt_u32_b32 (it adds its second operand), then the mid byte with one SDWA add: two
+	 * instructions per code after the mask where the compiler's own choice - v_bcnt(x, 0), a byte extract and a three-operand add - is
+	 * three (round 5; the empty asm keeps the intermediate sum apart, so the adds cannot be regrouped) */
+	const u32x4 p = sb.planes;
+	const int n = sb.n;
+	const uint32_t m = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+	const uint32_t a[4] = { ~p.x & ~p.y, p.x & ~p.y, ~p.x & p.y, p.x & p.y };
+	const uint32_t m2 = m & ~p.z, m2p = m & p.z;
+	const uint32_t b[4] = { m2 & ~p.w, m2p & ~p.w, m2 & p.w, m2p & p.w };
 	const uint32_t md[4] = { sb.mid.x, sb.mid.y, sb.mid.z, sb.mid.w };
+	uint32_t acc[16];
 #pragma unroll
 	for (int s = 0; s < 4; s++) { /* (slice s = the codes 2s, 2s+1, 2s+8, 2s+9) */
 		const u32x4 q = cnt_row[(s + crot) & 7];
-		acc[2 * s] += q.x + (md[s] & 255u); acc[2 * s + 1] += q.y + ((md[s] >> 8) & 255u);
-		acc[2 * s + 8] += q.z + ((md[s] >> 16) & 255u); acc[2 * s + 9] += q.w + (md[s] >> 24);
+		const int c0 = 2 * s, c1 = 2 * s + 1, c2 = 2 * s + 8, c3 = 2 * s + 9;
+		uint32_t t0 = (uint32_t)__popc(a[c0 & 3] & b[c0 >> 2]) + q.x, t1 = (uint32_t)__popc(a[c1 & 3] & b[c1 >> 2]) + q.y;
+		uint32_t t2 = (uint32_t)__popc(a[c2 & 3] & b[c2 >> 2]) + q.z, t3 = (uint32_t)__popc(a[c3 & 3] & b[c3 >> 2]) + q.w;
+		asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+		acc[c0] = t0 + (md[s] & 255u); acc[c1] = t1 + ((md[s] >> 8) & 255u);
+		acc[c2] = t2 + ((md[s] >> 16) & 255u); acc[c3] = t3 + (md[s] >> 24);
 	}
 	if (quirk) { acc[5] = sb.first == 5u ? 0u : 1u; acc[9] = sb.first == 9u ? 0u : 1u; acc[11] = sb.first == 11u ? 0u : 1u; acc[13] = sb.first == 13u ? 0u : 1u; }
 #pragma unroll
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 					 * equal widths) when there is no such read. */
 					uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
 					for (int k = -2; k < len; k++) /* (down to k = -2: the hit check, i = 0, of a read shorter than the seed consults D_seed too, :324-328) */
-						if (k - (len - kp.seed_length) >= 0) rec_put(rec, 8, k, 0x80u);
+						if (k - (len - kp.seed_length) >= 0) rec_put(rec, rec_count((uint32_t)len), 8, k, 0x80u);
 				}
 				if (active && kp.use_precalc) /* -P: a read with an N in the last 12 bases of rc is dropped before calculate_d (inexact_match.c:129-136) */
 					for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) active = false;
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 			{ /* D[k] is what an entry with e->i == k+1 reads as D[i-1] and one with e->i == k+2 as D[i-2] (:317,399-405) */
 				const uint32_t byte = (uint32_t)((z > 127 ? 127 : z) | ((k > 0 && nm == prev_nm) ? 0x80 : 0));
 				uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
-				rec_put(rec, phase ? 8 : 0, phase ? k + (len - kp.seed_length) : k, byte); /* (seed: its index k at the read's position k + len - seed_length) */
+				rec_put(rec, rec_count((uint32_t)len), phase ? 8 : 0, phase ? k + (len - kp.seed_length) : k, byte); /* (seed: its index k at the read's position k + len - seed_length) */
 				if (!phase) { /* seq[len - i1], i1 = k + 1: the complement of the base an entry at i1 extends with (io.c:502-504); four positions share 16 bits */
 					const int i1 = k + 1;
 					bacc |= (uint32_t)c << (4 * (i1 & 3));

@@ -33,12 +33,17 @@ void store_bwt(const bwt_t *BWT, const char *bwtFname) {
 /* ---- loading: the file is read by several threads in units of LOAD_UNIT blocks, in file order; blocks_ready follows the leading
  * complete units, so that a GPU context (bwb_hip_ctx_create_streamed) can upload the head of the index while the tail is still being
  * read.  The reference freads the file from one thread (bwt.c:90-125): 12 GB at GRCh37 scale. */
-#define LOAD_UNIT (1ull << 17) /* 128-character blocks per unit: 8 MB of bwt words + 16 MB of O rows */
+#define LOAD_UNIT_DEFAULT (1ull << 17) /* 128-character blocks per unit: 8 MB of bwt words + 16 MB of O rows */
+static uint64_t load_unit(void) { /* (BWB_LOAD_UNIT: a test knob - a unit of a few blocks runs the multi-unit logic on the toy index) */
+	const char *e = getenv("BWB_LOAD_UNIT");
+	const uint64_t v = e ? strtoull(e, NULL, 10) : 0;
+	return v ? v : LOAD_UNIT_DEFAULT;
+}
 typedef struct {
 	bwt_t *B;
 	int fd;
 	char *fname;
-	uint64_t n_units, next_unit, off_bwt, off_O, off_SA;
+	uint64_t n_units, next_unit, off_bwt, off_O, off_SA, unit;
 	int load_sa, sa_done;
 	unsigned char *done;
 	pthread_mutex_t mu;
@@ -68,6 +73,7 @@ static void *bwt_loader_thread(void *arg) {
 			if (do_sa) pread_all(L->fd, B->SA, B->num_sa * sizeof(bwtint_t), L->off_SA, L->fname);
 			return NULL;
 		}
+		const uint64_t LOAD_UNIT = L->unit;
 		const uint64_t b0 = u * LOAD_UNIT, nb = (B->num_occ - b0) < LOAD_UNIT ? (B->num_occ - b0) : LOAD_UNIT;
 		const uint64_t w0 = b0 * 16, nw = (B->num_words - w0) < nb * 16 ? (B->num_words - w0) : nb * 16;
 		pread_all(L->fd, B->bwt + w0, nw * sizeof(uint32_t), L->off_bwt + w0 * sizeof(uint32_t), L->fname);
@@ -92,6 +98,11 @@ bwt_t *load_bwt_start(const char *bwtFname, int loadSA) {
 	memcpy(B->C, hdr + 5, sizeof(bwtint_t) * (ALPHABET_SIZE + 1));
 	B->bwt = (uint32_t *)malloc((B->num_words ? B->num_words : 1) * sizeof(uint32_t));
 	B->O = (bwtint_t *)malloc((B->num_occ ? B->num_occ : 1) * ALPHABET_SIZE * sizeof(bwtint_t));
+	/* the header must be consistent BEFORE a loader thread computes a read size from it (bwt.c:161-218 writes exactly these; a crafted
+	 * num_words < 16 * (num_occ - 1) would make a unit's word count underflow) */
+	if (B->length < 2 || B->num_occ != (B->length + 127) / 128 || B->num_words != (B->length + 7) / 8 || B->num_sa != (B->length + 31) / 32 || B->sa0_index >= B->length)
+		bwb_die("load_bwt: %s: inconsistent header (length %llu, num_words %llu, num_sa %llu, num_occ %llu)", bwtFname, (unsigned long long)B->length,
+		        (unsigned long long)B->num_words, (unsigned long long)B->num_sa, (unsigned long long)B->num_occ);
 	if (!B->bwt || !B->O) bwb_die("load_bwt: Could not allocate memory for the BWT index. ");
 	if (loadSA) {
 		B->SA = (bwtint_t *)malloc((B->num_sa ? B->num_sa : 1) * sizeof(bwtint_t));
@@ -104,7 +115,8 @@ bwt_t *load_bwt_start(const char *bwtFname, int loadSA) {
 		struct stat st;
 		if (fstat(fd, &st) || (uint64_t)st.st_size < L->off_SA + (loadSA ? B->num_sa * sizeof(bwtint_t) : 0)) bwb_die("load_bwt: Could not read BWT from file: %s!", bwtFname);
 	}
-	L->n_units = (B->num_occ + LOAD_UNIT - 1) / LOAD_UNIT;
+	L->unit = load_unit();
+	L->n_units = (B->num_occ + L->unit - 1) / L->unit;
 	L->done = (unsigned char *)calloc(L->n_units ? L->n_units : 1, 1);
 	pthread_mutex_init(&L->mu, NULL);
 	long nc = sysconf(_SC_NPROCESSORS_ONLN);

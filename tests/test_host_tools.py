@@ -343,6 +343,33 @@ def test_threaded_bwt_loader_reads_the_file_exactly(built, golden, tmp_path, mon
         assert open(out, "rb").read() == open(os.path.join(golden, "toy.fa.bwt"), "rb").read()
 
 
+@pytest.mark.parametrize("unit,threads", [("7", "5"), ("1", "16"), ("100", "3"), ("3129", "2"), ("3130", "4")])
+def test_threaded_bwt_loader_with_many_small_units(built, golden, tmp_path, monkeypatch, unit, threads):
+    """the multi-unit logic of host/bwt_io.c (units completing out of order, blocks_ready advancing over the leading complete units,
+    the partial last unit) on the toy index: 3 130 blocks read in units of a few blocks (BWB_LOAD_UNIT) by up to 16 threads.  With the
+    default unit (2^17 blocks) the toy index is one unit and only the GRCh37-size GPU tests ever ran this code."""
+    out = tmp_path / "copy.bwt"
+    monkeypatch.setenv("BWB_LOAD_THREADS", threads)
+    monkeypatch.setenv("BWB_LOAD_UNIT", unit)
+    run([bw.HOST_BIN, "bwtcat", os.path.join(golden, "toy.fa.bwt"), str(out)])
+    assert open(out, "rb").read() == open(os.path.join(golden, "toy.fa.bwt"), "rb").read()
+
+
+def test_bwt_loader_refuses_an_inconsistent_header(built, golden, tmp_path):
+    """a header whose num_words does not belong to its length is refused before any loader thread sizes a read from it (a
+    small num_words with a large num_occ made a unit's word count underflow and pread write past the array)"""
+    import struct
+    src = open(os.path.join(golden, "toy.fa.bwt"), "rb").read()
+    hdr = list(struct.unpack("<5Q", src[:40]))
+    for field, val in ((1, 16), (3, hdr[3] + 1000), (2, 1), (0, 1), (4, hdr[0])):
+        bad = list(hdr)
+        bad[field] = val
+        path = tmp_path / f"bad{field}.bwt"
+        open(path, "wb").write(struct.pack("<5Q", *bad) + src[40:])
+        r = subprocess.run([bw.HOST_BIN, "bwtcat", str(path), str(tmp_path / "o.bwt")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode != 0 and "load_bwt" in r.stdout, (field, r.returncode, r.stdout[-200:])
+
+
 @pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln"])
 def test_aln_reader_and_writer_round_trip(built, golden, tmp_path, aln):
     """host/aln_io.c without a GPU.  The reference's loader fills aln_path in pair order (align.c:466-476), i.e. it holds the

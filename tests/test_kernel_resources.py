@@ -13,10 +13,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+BUILD = os.path.join(ROOT, "bwbble_amd", "build")
+
+
+def kept(name):
+    """the assembly and the resource remarks that `make` kept from the hipcc invocation that produced the shipped library `name` (and on
+    which the Makefile rule has already run the proof: a library that fails it is deleted)"""
+    import subprocess
+    import check_prefetch_regs as cpr
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "bwbble_amd"), "all", "testlib"], check=True)
+    d = os.path.join(BUILD, name)
+    return cpr.check_asm(os.path.join(d, "bwb_hip-hip-amdgcn-amd-amdhsa-gfx950.s"), remarks_file=os.path.join(d, "remarks.txt"))
+
+
 @pytest.fixture(scope="module")
 def compiled():
-    import check_prefetch_regs as cpr
-    return cpr.check_all()
+    return kept("lib")
 
 
 def test_prefetched_registers_are_not_read_before_the_wait(compiled):
@@ -29,8 +41,7 @@ def test_prefetched_registers_are_not_read_before_the_wait(compiled):
 
 def test_prefetched_registers_in_the_test_build():
     """the small-superblock test build (make testlib) is a different compilation: the same proof for it"""
-    import check_prefetch_regs as cpr
-    res, _ = cpr.check_all(["-DBWB_SB_SHIFT=13", "-DBWB_TEST_POS_BIAS=0x500000000ull"])
+    res, _ = kept("testlib")
     assert len(res) == 8
     for k, (sites, errs) in res.items():
         assert sites >= 2 and not errs, (k, errs)
@@ -49,6 +60,16 @@ def test_search_kernel_register_budget(compiled):
     head = [v for k, v in ks.items() if "kl_searchImLb0ELb1E" in k][0]  # 64-bit positions (GRCh37 scale), 16-byte heap entries (-o <= 1), multi-genome
     # no vector register spilled and no scratch instruction in it (the frame itself may keep a few bytes that nothing touches)
     assert head["VGPRs Spill"] == 0 and head["ScratchOps"] == 0 and head["ScratchSize"] <= 64, head
+
+
+def test_the_shipped_libraries_are_the_checked_ones():
+    """the proof is about the .so that ships: the assembly is kept by the same hipcc invocation, and is not older than the library"""
+    for name, so in (("lib", "libbwbble_hip.so"), ("testlib", "libbwbble_hip_test.so")):
+        kept(name)
+        d = os.path.join(BUILD, name)
+        so_path = os.path.join(ROOT, "bwbble_amd", so)
+        assert os.path.exists(so_path) and "HAZARD" not in open(os.path.join(d, "prefetch_check.txt")).read()
+        assert abs(os.path.getmtime(so_path) - os.path.getmtime(os.path.join(d, "bwb_hip-hip-amdgcn-amd-amdhsa-gfx950.s"))) < 120
 
 
 def test_checker_sees_a_hazard():

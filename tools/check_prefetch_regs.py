@@ -12,7 +12,10 @@ gather's wait); this script proves it for the code hipcc actually generated, for
     `s_waitcnt` with vmcnt(0) is met on the path; any instruction on the way that names a register of vD (as a source or as a
     destination) is an error - except the other prefetch sites' own loads into their own registers.
 
-usage: check_prefetch_regs.py [-D<flag> ...]      exit code 0 = clean; prints one line per kernel"""
+usage: check_prefetch_regs.py --asm <file.s> [--remarks <file>]   the assembly (and the compiler's remarks) that bwbble_amd/Makefile kept from the
+                                                                  hipcc invocation that produced the shipped .so: what `make` runs, and fails on
+       check_prefetch_regs.py [-D<flag> ...]                      compile here with extra flags (experiment builds)
+exit code 0 = clean; prints one line per kernel"""
 import os
 import re
 import subprocess
@@ -31,23 +34,35 @@ def compile_isa(flags, remarks=None):
            "--save-temps", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "lib.so"), SRC] + flags
     r = subprocess.run(cmd, cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     if remarks is not None:
-        cur = None
-        for ln in r.stderr.splitlines():
-            m = re.search(r"Function Name: (\S+)", ln)
-            if m:
-                cur = m.group(1)
-                remarks[cur] = {}
-                continue
-            m = re.search(r"\s{2,}([A-Za-z][A-Za-z ]*?)(?: \[[^\]]*\])?: (\d+) \[-Rpass", ln)
-            if m and cur:
-                remarks[cur][m.group(1).strip()] = int(m.group(2))
+        parse_remarks(r.stderr, remarks)
     return os.path.join(d, "bwb_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
+def parse_remarks(text, remarks):
+    cur = None
+    for ln in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            cur = m.group(1)
+            remarks[cur] = {}
+            continue
+        m = re.search(r"\s{2,}([A-Za-z][A-Za-z ]*?)(?: \[[^\]]*\])?: (\d+) \[-Rpass", ln)
+        if m and cur:
+            remarks[cur][m.group(1).strip()] = int(m.group(2))
+
+
 def check_all(flags=()):
-    """-> ({kernel: (sites, [errors])}, {kernel: resource remarks}) for every kl_search instantiation"""
+    """-> ({kernel: (sites, [errors])}, {kernel: resource remarks}) for every kl_search instantiation, compiled here"""
     remarks = {}
     path = compile_isa(list(flags), remarks)
+    return check_asm(path, remarks)
+
+
+def check_asm(path, remarks=None, remarks_file=None):
+    """the same for an assembly file that a build kept (bwbble_amd/build/<lib>/: the .s of the very hipcc invocation that made the .so)"""
+    remarks = {} if remarks is None else remarks
+    if remarks_file and os.path.exists(remarks_file):
+        parse_remarks(open(remarks_file).read(), remarks)
     cur, kernels = None, {}
     for ln in open(path):
         m = re.match(r"^(_Z\w*kl_search\w*):", ln)
@@ -136,7 +151,12 @@ def check_kernel(name, body):
 
 def main():
     flags = [a for a in sys.argv[1:] if a.startswith("-D")]
-    res, remarks = check_all(flags)
+    if "--asm" in sys.argv:
+        asm = sys.argv[sys.argv.index("--asm") + 1]
+        rem = sys.argv[sys.argv.index("--remarks") + 1] if "--remarks" in sys.argv else None
+        res, remarks = check_asm(asm, remarks_file=rem)
+    else:
+        res, remarks = check_all(flags)
     bad = 0
     for k, (n, errs) in res.items():
         ru = remarks.get(k, {})
