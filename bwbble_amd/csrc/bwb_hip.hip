@@ -298,8 +298,9 @@ extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 
 static size_t lane_lds(const bwb_hip_ctx *c) {
 	(void)c;
-	return (size_t)LDS_WAVES_OFF + (size_t)(LANE_BLOCK / 64) * WAVE_LDS_BYTES; /* base table + zero row + per wave: gather staging / children */
+	return (size_t)LDS_WAVES_OFF + (size_t)(LANE_BLOCK / 64) * WAVE_LDS_BYTES + LDS_ALIGN_SLACK; /* base table + zero row + per wave: gather staging / children */
 }
+static size_t calcd_lds(void) { return (size_t)CALCD_LDS_BYTES; } /* kl_calc_d's own map: one base table, its own number of compacted U rows (bwb_lane.h) */
 
 static uint32_t max_reads_resident(const bwb_hip_ctx *c) {
 	uint32_t n = 1;
@@ -356,7 +357,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 		 * while nothing is parked (the grid, and with it the pool geometry, is fixed for the life of a stream). */
 		if (!s.ready || !c->parked) {
 			c->bpc_search = c->kp.max_diff > 3 ? std::min(2, LANE_WAVES_PER_SIMD) : LANE_WAVES_PER_SIMD;
-			c->bpc_calcd = LANE_WAVES_PER_SIMD;
+			c->bpc_calcd = CALCD_WAVES_PER_SIMD;
 			if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
 			if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));
 			if (getenv("BWB_CALCD_BLOCKS_PER_CU")) c->bpc_calcd = std::max(1, atoi(getenv("BWB_CALCD_BLOCKS_PER_CU")));
@@ -365,21 +366,24 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 			 * the runtime says fit (registers, LDS) - and never more than the LDS really holds: the runtime's answer was 3 for a block
 			 * size of which the hardware placed 2 (allocation in units of 1 280 bytes; profiles/r4_lds_probe.txt), which cost 13 % unnoticed. */
 			int occ = 0;
-			auto lds_fit = [&](const void *f) {
+			auto lds_fit = [&](const void *f, size_t dyn) {
 				hipFuncAttributes fa;
 				if (hipFuncGetAttributes(&fa, f) != hipSuccess) return LANE_WAVES_PER_SIMD;
-				const size_t need = ((fa.sharedSizeBytes + lane_lds(c) + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE;
+				const size_t need = ((fa.sharedSizeBytes + dyn + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE;
 				return (int)std::max<size_t>(1, LDS_CU_BYTES / need);
 			};
 			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true, true> : (const void *)kl_search<uint32_t, false, true>)
 			                          : (c->wide ? (const void *)kl_search<uint64_t, true, true> : (const void *)kl_search<uint64_t, false, true>); /* (the -S instantiations need no more) */
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
 				if (c->dbg && !s.ready) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU\n", occ, LANE_BLOCK);
-				c->bpc_search = std::min(c->bpc_search, std::min(occ, lds_fit(kf)));
-				if (c->dbg && !s.ready && lds_fit(kf) < occ) fprintf(stderr, "[bwb] kl_search: only %d block(s) per CU by LDS granules\n", lds_fit(kf));
+				c->bpc_search = std::min(c->bpc_search, std::min(occ, lds_fit(kf, lane_lds(c))));
+				if (c->dbg && !s.ready && lds_fit(kf, lane_lds(c)) < occ) fprintf(stderr, "[bwb] kl_search: only %d block(s) per CU by LDS granules\n", lds_fit(kf, lane_lds(c)));
 			}
 			const void *kd = c->pos32 ? (const void *)kl_calc_d<uint32_t> : (const void *)kl_calc_d<uint64_t>;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) c->bpc_calcd = std::min(c->bpc_calcd, std::min(occ, lds_fit(kd)));
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kd, LANE_BLOCK, calcd_lds()) == hipSuccess && occ >= 1) {
+				c->bpc_calcd = std::min(c->bpc_calcd, std::min(occ, lds_fit(kd, calcd_lds())));
+				if (c->dbg && !s.ready) fprintf(stderr, "[bwb] kl_calc_d: %d block(s) per CU (occupancy query %d, LDS granules %d)\n", c->bpc_calcd, occ, lds_fit(kd, calcd_lds()));
+			}
 		}
 		/* (the scratch is sized for the larger grid: the two kernels share it) */
 		blocks = (uint32_t)(c->num_cu * std::max(LANE_WAVES_PER_SIMD, std::max(c->bpc_search, c->bpc_calcd))); lcap = 4096; acap = 256;
@@ -583,7 +587,7 @@ static int launch_calc_d(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 	HIPCHK(hipMemsetAsync(counter, 0, 4, c->stream));
 	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_calcd) : sc.blocks;
 	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
-	const size_t lds = lane_lds(c);
+	const size_t lds = calcd_lds();
 	hipEvent_t e0 = get_event(c), e1 = get_event(c);
 	if (!e0 || !e1) return fail(BWB_E_HIP, "hipEventCreate failed");
 	c->pending.push_back(PendingTime{ e0, e1, 0 });

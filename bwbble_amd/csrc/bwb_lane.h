@@ -87,9 +87,11 @@ struct LaneScratch {
 #ifndef NU_MAX
 #define NU_MAX 24 /* compacted U rows per round (a multiple of 8, at most 32: the exchange array holds four per column) */
 #endif
-#define WAVE_STAGE_U4 (64 * 8 + NU_MAX * 8)
-#define WAVE_XCH_OFF (WAVE_STAGE_U4 * 16)
-#define WAVE_LDS_BYTES (WAVE_XCH_OFF + 512)
+/* (the number of U rows is a template parameter of the gather: kl_search and kl_calc_d choose their own, CALCD_NU below) */
+#define WAVE_XCH_OFF_NU(nu) ((64 * 8 + (nu) * 8) * 16)
+#define WAVE_LDS_BYTES_NU(nu) (WAVE_XCH_OFF_NU(nu) + 512)
+#define WAVE_XCH_OFF WAVE_XCH_OFF_NU(NU_MAX)
+#define WAVE_LDS_BYTES WAVE_LDS_BYTES_NU(NU_MAX)
 /* block-level LDS in front of the waves' areas: the base table, then one all-zero 128-byte row that stands in for the bucket of a
  * position that needs none (-1, length-1, an idle lane): counts 0, no characters */
 /* (after the base table its superblock rows a second time, as O_alphabet sees them - load_base2 -; kl_calc_d only reads the first.  LDS is
@@ -102,8 +104,21 @@ struct LaneScratch {
  * three), static LDS of the kernel included (kl_search: 160 bytes). */
 #define LDS_CU_BYTES 163840
 #define LDS_GRANULE 1280
-static_assert(3 * (((LDS_WAVES_OFF + 4 * WAVE_LDS_BYTES + 256 + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE) <= LDS_CU_BYTES, "three blocks of four waves per CU no longer fit the LDS");
+static_assert(3 * (((LDS_WAVES_OFF + 4 * WAVE_LDS_BYTES + 128 + 256 + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE) <= LDS_CU_BYTES, "three blocks of four waves per CU no longer fit the LDS");
 
+/* kl_calc_d has its own LDS map: the first base table only (exact counts), the zero row, then its waves' areas with CALCD_NU compacted U rows.
+ * CALCD_WAVES_PER_SIMD = 4 needs at most 40 960 bytes per block (32 granules): 1 408 + 4 x 9 728 = 40 320 with 8 U rows. */
+#ifndef CALCD_NU
+#define CALCD_NU NU_MAX
+#endif
+#ifndef CALCD_WAVES_PER_SIMD
+#define CALCD_WAVES_PER_SIMD LANE_WAVES_PER_SIMD
+#endif
+#define CALCD_ZERO_OFF (BWB_BASE_ROWS * 16 * 8)
+#define CALCD_WAVES_OFF (CALCD_ZERO_OFF + 128)
+#define LDS_ALIGN_SLACK 128 /* the kernels align their dynamic LDS to 128 bytes themselves */
+#define CALCD_LDS_BYTES (CALCD_WAVES_OFF + (LANE_BLOCK / 64) * WAVE_LDS_BYTES_NU(CALCD_NU) + LDS_ALIGN_SLACK)
+static_assert(CALCD_WAVES_PER_SIMD * (((CALCD_LDS_BYTES + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE) <= LDS_CU_BYTES, "kl_calc_d: its blocks per CU no longer fit the LDS");
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); /* (a plain vector: HIP's uint4 class has no LDS-address-space operators) */
 typedef __attribute__((address_space(3))) unsigned char *LdsBytes;
 
@@ -147,16 +162,17 @@ __device__ __forceinline__ void pair_setup(P last_row, bool need, P pL, P pU, in
  * 128 contiguous bytes instead of 64 different ones (measured on a 7 GiB table: 50 G buckets/s this way against 10.9 G/s when every
  * lane loads its own bucket with 8 x dwordx4 - that shape is bound by address translation, 64 pages per instruction).  The loads
  * are global_load_lds_dwordx4: memory -> LDS without a register in between, all in flight together; such a load writes LDS at
- * base + 16 * lane, so to keep the owners' 128-bit reads off each other's banks the slices of row o are rotated by (o >> 1) & 7 on
- * the SOURCE side.  Which bucket an owner wants travels through the wave's exchange array (written transposed, so that a lane reads
+ * base + 16 * lane, so to keep the owners' 128-bit reads off each other's banks the slices of row o are permuted on the SOURCE side: slot p
+ * of row o holds slice p ^ rot(o), rot(o) = (o >> 1) & 7 (round 5: an XOR, where rounds 3-4 rotated by an addition - with rows that are
+ * 128-byte aligned the address of slice s of a row is then (row + 16 rot) ^ 16 s, ONE instruction instead of add / and / shift-add: RowRef).  Which bucket an owner wants travels through the wave's exchange array (written transposed, so that a lane reads
  * the 8 owners of its column with 128-bit reads; round 2 used 16 ds_bpermute).
  * Round `first` == 0 fetches the L rows and the U rows of the compacted owners [0, NU_MAX); a later round (first = NU_MAX, ...)
  * only the U rows of the owners [first, first + NU_MAX).  Called by EVERY lane of the wave. */
-template <typename P>
+template <typename P, int NU = NU_MAX>
 __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, const PairInfo<P> &pi, int first, Lds<u32x4> stage, int lane) {
 	const int sub = lane >> 3, p = lane & 7;
-	Lds<uint32_t> xch = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF); /* [0,64): L owners, [64,128): U owners, both transposed: owner o at (o & 7) * 8 + (o >> 3) */
-	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU_MAX;
+	Lds<uint32_t> xch = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF_NU(NU)); /* [0,64): L owners, [64,128): U owners, both transposed: owner o at (o & 7) * 8 + (o >> 3) */
+	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU;
 	const uint32_t k = pi.ku - (uint32_t)first;
 	/* (the exchange array carries bucket << 3, the bucket's index in 16-byte slices - one add and one shift-add make the address; a bucket
 	 * number has 28 bits, NONE32 stays NONE32) */
@@ -172,8 +188,8 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	uint32_t sv = (uint32_t)(uintptr_t)stage;
 	asm volatile("" : "+v"(sv)); /* (not loop-invariant for the compiler: a scalar kept across the loop would be one more spilled SGPR) */
 	const uint32_t sbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv);
-	/* slice of instruction r = (p - ((8 r + sub) >> 1)) & 7 = (p - (sub >> 1) - 4 r) & 7: two values, for even and for odd r */
-	const uint32_t sl0 = (uint32_t)((p - (sub >> 1)) & 7), sl1 = sl0 ^ 4u;
+	/* slice of instruction r = p ^ rot(8 r + sub) = p ^ ((sub >> 1) + 4 (r & 1)) = p ^ (sub >> 1) ^ 4 (r & 1): two values, for even and for odd r */
+	const uint32_t sl0 = (uint32_t)(p ^ (sub >> 1)), sl1 = sl0 ^ 4u;
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 #pragma unroll
 	for (int r = 0; r < 8; r++) {
@@ -182,7 +198,7 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	}
 	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
 #pragma unroll
-	for (int r = 0; r < NU_MAX / 8; r++) {
+	for (int r = 0; r < NU / 8; r++) {
 		const uint32_t slice = (r & 1) ? sl1 : sl0;
 		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
@@ -213,20 +229,25 @@ struct SideBits {
 	uint32_t first;  /* first character of the enclosing 128-character block */
 	int n;           /* characters of the sub-block to count: (off & 31) + 1 */
 };
-__device__ __forceinline__ void side_read(Lds<u32x4> row, int rot, int off, SideBits &sb) {
-	const int w = off >> 5;
-	sb.planes = row[(4 + w + rot) & 7];
-	const u32x4 md = row[(6 + rot) & 7];
+/* A row of the staging area as its readers name it: R = the row's byte address in LDS (128-byte aligned) + 16 rot(row); slice s is at
+ * R ^ 16 s (see wave_gather), word w of the row's logical contents at R ^ 4 w. */
+typedef uint32_t RowRef;
+__device__ __forceinline__ RowRef row_ref(Lds<u32x4> stage, uint32_t row) { return (uint32_t)(uintptr_t)stage + (row << 7) + ((row << 3) & 0x70u); }
+__device__ __forceinline__ Lds<u32x4> row_slice(RowRef R, uint32_t s16) { return (Lds<u32x4>)(uintptr_t)(R ^ s16); }
+__device__ __forceinline__ void side_read(RowRef R, int off, SideBits &sb) {
+	const uint32_t w16 = ((uint32_t)off >> 1) & 0x10u; /* 16 x (off >> 5), off < 64 */
+	sb.planes = *row_slice(R, 0x40u | w16);
+	const u32x4 md = *row_slice(R, 0x60u);
 	const u32x4 z = { 0u, 0u, 0u, 0u };
-	sb.mid = w ? md : z;
-	sb.first = ((Lds<uint32_t>)(row + ((7 + rot) & 7)))[0];
+	sb.mid = w16 ? md : z;
+	sb.first = *(Lds<uint32_t>)(uintptr_t)(R ^ 0x70u);
 	sb.n = (off & 31) + 1;
 }
 /* rel[j] = count of j before the bucket (slices 0-3 of `cnt_row`, count-slice order) + mid + pass, for j = 0..15 IN CODE ORDER -> slices
  * `dst0` .. `dst0 + 3` of the lane's own row (slice k holds the codes 4k .. 4k+3: kid_get finds code j with three instructions; round 3
  * left them in the count-slice order, whose address arithmetic cost more than the rank's adds); `quirk`: O_alphabet's view of 5, 9, 11, 13.
  * Every count slice is read before the first result is written: the row is source and destination. */
-__device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const SideBits &sb, bool quirk, Lds<u32x4> own, int rot, int dst0) {
+__device__ __forceinline__ void side_finish(RowRef cntR, const SideBits &sb, bool quirk, RowRef ownR, int dst0) {
 	/* acc[c] = count slice + popcount in ONE v_bcnt_u32_b32 (it adds its second operand), then the mid byte with one SDWA add: two
 	 * instructions per code after the mask where the compiler's own choice - v_bcnt(x, 0), a byte extract and a three-operand add - is
 	 * three (round 5; the empty asm keeps the intermediate sum apart, so the adds cannot be regrouped) */
@@ -240,7 +261,7 @@ __device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const 
 	uint32_t acc[16];
 #pragma unroll
 	for (int s = 0; s < 4; s++) { /* (slice s = the codes 2s, 2s+1, 2s+8, 2s+9) */
-		const u32x4 q = cnt_row[(s + crot) & 7];
+		const u32x4 q = *row_slice(cntR, (uint32_t)s << 4);
 		const int c0 = 2 * s, c1 = 2 * s + 1, c2 = 2 * s + 8, c3 = 2 * s + 9;
 		uint32_t t0 = (uint32_t)__popc(a[c0 & 3] & b[c0 >> 2]) + q.x, t1 = (uint32_t)__popc(a[c1 & 3] & b[c1 >> 2]) + q.y;
 		uint32_t t2 = (uint32_t)__popc(a[c2 & 3] & b[c2 >> 2]) + q.z, t3 = (uint32_t)__popc(a[c3 & 3] & b[c3 >> 2]) + q.w;
@@ -248,26 +269,28 @@ __device__ __forceinline__ void side_finish(Lds<u32x4> cnt_row, int crot, const 
 		acc[c0] = t0 + (md[s] & 255u); acc[c1] = t1 + ((md[s] >> 8) & 255u);
 		acc[c2] = t2 + ((md[s] >> 16) & 255u); acc[c3] = t3 + (md[s] >> 24);
 	}
-	if (quirk) { acc[5] = sb.first == 5u ? 0u : 1u; acc[9] = sb.first == 9u ? 0u : 1u; acc[11] = sb.first == 11u ? 0u : 1u; acc[13] = sb.first == 13u ? 0u : 1u; }
+	{ /* O_alphabet's view of the codes 5, 9, 11, 13: 1 - [first char of the block == j] (bit j of ~(1 << first)); selects, no branch */
+		const uint32_t nh = ~(1u << (sb.first & 31u));
+		acc[5] = quirk ? ((nh >> 5) & 1u) : acc[5]; acc[9] = quirk ? ((nh >> 9) & 1u) : acc[9];
+		acc[11] = quirk ? ((nh >> 11) & 1u) : acc[11]; acc[13] = quirk ? ((nh >> 13) & 1u) : acc[13];
+	}
 #pragma unroll
-	for (int k = 0; k < 4; k++) own[(dst0 + k + rot) & 7] = u32x4{ acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3] };
+	for (int k = 0; k < 4; k++) *row_slice(ownR, (uint32_t)(dst0 + k) << 4) = u32x4{ acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3] };
 }
 /* index of code j in the count-slice order */
 __device__ __forceinline__ constexpr int cslot(int j) { return 4 * ((j & 7) >> 1) + (j & 1) + 2 * (j >> 3); }
 
 /* where a lane's children are after wave_children */
 template <typename P> struct KidCtx {
-	Lds<uint32_t> row;     /* the lane's row: relL in slices 0-3, relU in slices 4-7 (code order: slice k = codes 4k .. 4k+3; rotated by the lane's rot) */
-	int rot;
+	RowRef R;              /* the lane's row: relL in slices 0-3, relU in slices 4-7 (code order: slice k = codes 4k .. 4k+3) */
 	Lds<P> baseL, baseU;   /* base-table rows of the two positions */
 	bool qL, qU;           /* O_alphabet's view of the codes 5, 9, 11, 13 applies to this side: value = C[j] - [first char of the block == j] */
 };
 /* child j = [vL(j) + 1, vU(j)] */
 template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &kc, Lds<P> s_base, int j, P &L, P &U) {
-	/* code j: component j & 3 of slice (j >> 2) + rot (mod 8); relU four slices on, i.e. the same byte offset with bit 6 flipped */
-	const uint32_t x = (uint32_t)j << 2;
-	const uint32_t offL = ((((x & 0x30u) + ((uint32_t)kc.rot << 4)) & 0x70u) | (x & 0xCu));
-	const uint32_t rl = *(Lds<uint32_t>)((LdsBytes)kc.row + offL), ru = *(Lds<uint32_t>)((LdsBytes)kc.row + (offL ^ 0x40u));
+	/* code j: word j of the row's logical contents (slice j >> 2, component j & 3) is at R ^ 4 j; relU four slices on: bit 6 flipped */
+	const uint32_t a = kc.R ^ ((uint32_t)j << 2);
+	const uint32_t rl = *(Lds<uint32_t>)(uintptr_t)a, ru = *(Lds<uint32_t>)(uintptr_t)(a ^ 0x40u);
 	/* (O_alphabet's view of the codes 5, 9, 11, 13 - value = C[j] - [first char of the block == j] - needs nothing here: side_finish left
 	 * rel = 1 - [first == j] and the side's base row is one of the second table, whose entries for these codes are C[j] - 1: load_base2.
 	 * Round 3 selected the row and the -1 per child: ten instructions; one extra row and a multiply-add: three, and 2 % slower than this) */
@@ -285,16 +308,15 @@ template <typename P> __device__ __forceinline__ void kid_get(const KidCtx<P> &k
  * in relative form in the lane's row (kid_get).  Returns the bitmask of non-empty children (bits 1..15); n_bkt += buckets
  * fetched for the WAVE (a wave-uniform counter).
  * Side U of a pair that shares its bucket with side L (five in six) is relL + #j among the characters (L-1, U]: the same planes. */
-template <typename P>
+template <typename P, int NU = NU_MAX>
 __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buckets, P last_row, bool need, P iL, P iU, bool alpha, Lds<P> s_base,
                                                   Lds<u32x4> stage, Lds<u32x4> zero_row, int lane, uint32_t &n_bkt, KidCtx<P> &kc) {
 	PairInfo<P> pi;
 	pair_setup<P>(last_row, need, (P)(iL - 1), iU, lane, pi);
 	n_bkt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_bkt + (uint32_t)__popcll(__ballot(pi.blkL != NONE32)) + (uint32_t)pi.nU)); /* (wave-uniform: the whole wave's buckets, added up by lane 0 at the end) */
-	wave_gather<P>(buckets, pi, 0, stage, lane);
-	const Lds<u32x4> own = stage + lane * 8;
-	const int rot = (lane >> 1) & 7;
-	kc.row = (Lds<uint32_t>)own; kc.rot = rot;
+	wave_gather<P, NU>(buckets, pi, 0, stage, lane);
+	const RowRef ownR = row_ref(stage, (uint32_t)lane), zeroR = (uint32_t)(uintptr_t)zero_row;
+	kc.R = ownR;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
 	/* (qL / qU imply a superblock row, 0 .. BWB_NSB_MAX - 1: the second table has just those) */
 	kc.baseL = s_base + pi.rowL * 16 + (kc.qL ? BWB_BASE_ROWS * 16 : 0); kc.baseU = s_base + pi.rowU * 16 + (kc.qU ? BWB_BASE_ROWS * 16 : 0);
@@ -304,33 +326,31 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	uint32_t ne = 0;
 	{
 		const bool haveL = pi.blkL != NONE32;
-		const Lds<u32x4> srcL = haveL ? own : zero_row;
-		const int rotL = haveL ? rot : 0;
+		const RowRef srcL = haveL ? ownR : zeroR;
 		SideBits bl;
-		side_read(srcL, rotL, pi.offL, bl);
-		for (int first = 0;; first += NU_MAX) {
-			if (first > 0) wave_gather<P>(buckets, pi, first, stage, lane); /* (rare: more than NU_MAX lanes of the wave with a second bucket) */
+		side_read(srcL, pi.offL, bl);
+		for (int first = 0;; first += NU) {
+			if (first > 0) wave_gather<P, NU>(buckets, pi, first, stage, lane); /* (rare: more than NU lanes of the wave with a second bucket) */
 			const bool fetched = pi.ku != NONE32;
-			const bool now = fetched ? ((int)pi.ku >= first && (int)pi.ku < first + NU_MAX) : first == 0;
+			const bool now = fetched ? ((int)pi.ku >= first && (int)pi.ku < first + NU) : first == 0;
 			if (now) {
 				const uint32_t k = pi.ku - (uint32_t)first;
-				const Lds<u32x4> src = fetched ? stage + 512 + k * 8 : (pi.same ? own : zero_row);
-				const int srot = fetched ? (int)((k >> 1) & 7) : (pi.same ? rot : 0);
+				const RowRef src = fetched ? row_ref(stage, 64u + k) : (pi.same ? ownR : zeroR);
 				SideBits bu;
-				side_read(src, srot, pi.offU, bu);
-				side_finish(src, srot, bu, kc.qU, own, rot, 4);
+				side_read(src, pi.offU, bu);
+				side_finish(src, bu, kc.qU, ownR, 4);
 			}
 			if (first == 0) {
 				__builtin_amdgcn_sched_barrier(0);
-				side_finish(srcL, rotL, bl, kc.qL, own, rot, 0); /* (a lane whose U row comes in a later round keeps relL in its row meanwhile) */
+				side_finish(srcL, bl, kc.qL, ownR, 0); /* (a lane whose U row comes in a later round keeps relL in its row meanwhile) */
 				__builtin_amdgcn_sched_barrier(0);
 			}
-			if (first + NU_MAX >= pi.nU) break;
+			if (first + NU >= pi.nU) break;
 		}
 		/* non-empty children, when both positions have the same base row: relU > relL (slice k holds the codes 4k .. 4k+3) */
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
-			const u32x4 l = own[(k + rot) & 7], q = own[(4 + k + rot) & 7];
+			const u32x4 l = *row_slice(ownR, (uint32_t)k << 4), q = *row_slice(ownR, (uint32_t)(4 + k) << 4);
 			ne |= (q.x > l.x ? 1u : 0u) << (4 * k) | (q.y > l.y ? 1u : 0u) << (4 * k + 1) | (q.z > l.z ? 1u : 0u) << (4 * k + 2) | (q.w > l.w ? 1u : 0u) << (4 * k + 3);
 		}
 	}
@@ -352,17 +372,24 @@ template <typename P> struct ListW {
 	P fL, fU;     /* the list's FIRST interval, once it is final (T >= 2): the step that reads this list next starts with it, and gets it from
 	                 here instead of loading what this step has just stored (kl_search) */
 };
-/* the list being built is the one the current step does not read: buffer base + sel * cap (no pointer kept in registers) */
-template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, int sel, P L, P U, int cap, bool &ovf) {
-	if (l.T != 0 && L == (P)(l.tU + 1)) { l.tU = U; return; }
-	if (l.T != 0) {
-		if (l.T - 1 >= cap) { ovf = true; return; }
-		Intv<P> *buf = base + sel * cap;
-		buf[l.T - 1].L = l.tL; buf[l.T - 1].U = l.tU;
-		if (l.T == 1) { l.fL = l.tL; l.fU = l.tU; }
-	}
-	l.tL = L; l.tU = U; l.T++;
+/* the list being built is the one the current step does not read: buffer base + sel * cap (no pointer kept in registers).
+ * One divergent region only - the store of a tail that cannot be merged -, everything else is selects: the loops that call this run
+ * several trips per wave iteration with a few lanes each (kl_calc_d: 5.4, kl_search's exact steps: 2.6, tools/bbprof.py), and the nest
+ * of four branches this was until round 4 cost more scalar mask bookkeeping per trip (25 instructions) than it did work. */
+template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, int sel, P L, P U, int cap) {
+	const bool has = l.T != 0;
+	const bool merge = has && L == (P)(l.tU + 1);
+	const bool flush = has && !merge;
+	if (flush) { Intv<P> *buf = base + sel * cap; buf[l.T - 1].L = l.tL; buf[l.T - 1].U = l.tU; }
+	const bool first = flush && l.T == 1;
+	l.fL = first ? l.tL : l.fL; l.fU = first ? l.tU : l.fU;
+	l.tL = merge ? l.tL : L;
+	l.tU = U;
+	l.T += merge ? 0 : 1;
 }
+/* room for the children of one more interval (at most 15 appends)?  Checked once per interval, ahead of its appends: a list that comes
+ * within 15 intervals of its capacity sends the read to the next scratch class a little early, which changes nothing but that. */
+template <typename P> __device__ __forceinline__ bool list_full(const ListW<P> &l, int cap) { return l.T + 15 > cap; }
 
 /* A read is finished: its status, hit count, offset and hit-log records are published BEFORE the slot's counter moves.  The
  * host polls that counter and copies the results on another stream while this kernel may still be running (a slot's parked reads
@@ -383,14 +410,15 @@ __device__ __forceinline__ uint32_t grab_read(const Work &wk) {
  * k_calc_d (one read per lane)
  * ========================================================================================== */
 template <typename P>
-__global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(DevIndex ix, Batch b, Work wk, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
+__global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(DevIndex ix, Batch b, Work wk, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
                                                         uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
-	extern __shared__ __align__(16) unsigned char smem[];
+	extern __shared__ __align__(16) unsigned char smem_[];
+	const LdsBytes smem = (LdsBytes)(uintptr_t)(((uint32_t)(uintptr_t)(LdsBytes)smem_ + 127u) & ~127u); /* (rows of the staging area are 128-byte aligned: RowRef; the host asks for 128 bytes more) */
 	P *s_base = (P *)smem;
 	const int lane = (int)(threadIdx.x & 63u);
-	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + (threadIdx.x >> 6) * WAVE_LDS_BYTES;
-	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(LdsBytes)(smem + LDS_ZERO_OFF);
-	const Lds<P> sb = (Lds<P>)(LdsBytes)smem; /* the base table again, as an LDS pointer */
+	LdsBytes wlds = smem + CALCD_WAVES_OFF + (threadIdx.x >> 6) * WAVE_LDS_BYTES_NU(CALCD_NU);
+	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(smem + CALCD_ZERO_OFF);
+	const Lds<P> sb = (Lds<P>)smem; /* the base table again, as an LDS pointer */
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
@@ -461,20 +489,21 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_calc_d(Dev
 		const bool need = active && c <= 3;
 		uint32_t nbk = 0;
 		KidCtx<P> kc;
-		uint32_t ne = wave_children<P>(buckets, last_row, need, iL, iU, false, sb, stage, zero_row, lane, nbk, kc); /* every lane of the wave loads */
+		uint32_t ne = wave_children<P, CALCD_NU>(buckets, last_row, need, iL, iU, false, sb, stage, zero_row, lane, nbk, kc); /* every lane of the wave loads */
 		n_bkt += nbk;
 		if (!active) { nxi_valid = false; continue; }
 		bool ovf = false;
 		if (c <= 3) {
 			r_vis += (pi_regular(last_row, (P)(iL - 1)) ? 1 : 0) + (pi_regular(last_row, iU) ? 1 : 0);
 			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
+			if (list_full<P>(nx, cap)) { ovf = true; ne = 0; }
 			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
 				const int j = __ffs((int)ne) - 1;
 				ne &= ne - 1;
 				P L, U;
 				kid_get<P>(kc, sb, j, L, U);
 				nm += (int32_t)(uint32_t)(U - L + 1);
-				list_add<P>(nx, lbase, cursel ^ 1, L, U, cap, ovf);
+				list_add<P>(nx, lbase, cursel ^ 1, L, U, cap);
 			}
 			s++;
 		}
@@ -884,13 +913,14 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define R_wk(f) (KARGS->wk.f)
 #define R_stats (KARGS->stats)
 #define R_sc(f) (KARGS->sc.f)
-	extern __shared__ __align__(16) unsigned char smem[];
+	extern __shared__ __align__(16) unsigned char smem_[];
+	const LdsBytes smem = (LdsBytes)(uintptr_t)(((uint32_t)(uintptr_t)(LdsBytes)smem_ + 127u) & ~127u); /* (rows of the staging area are 128-byte aligned: RowRef; the host asks for 128 bytes more) */
 	P *s_base = (P *)smem;
 	const int lane = (int)(threadIdx.x & 63u);
 	const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* (wave-uniform: a scalar) */
-	LdsBytes wlds = (LdsBytes)(smem + LDS_WAVES_OFF) + wave_in_block * WAVE_LDS_BYTES;
-	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(LdsBytes)(smem + LDS_ZERO_OFF);
-	const Lds<P> sb = (Lds<P>)(LdsBytes)smem; /* the base table again, as an LDS pointer */
+	LdsBytes wlds = smem + LDS_WAVES_OFF + wave_in_block * WAVE_LDS_BYTES;
+	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(smem + LDS_ZERO_OFF);
+	const Lds<P> sb = (Lds<P>)smem; /* the base table again, as an LDS pointer */
 	__shared__ unsigned long long s_blockfree;
 	__shared__ unsigned int s_active, s_nfree, s_left; /* reads in flight in this block; chunks on its recycle stack; waves that have left */
 	__shared__ unsigned int s_need_sum, s_need_cnt;    /* chunks (in units of 16) the reads finished by this block took, and how many reads: admission */
@@ -1248,7 +1278,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(2);
 		HISTW(H_WAVE_NREQ_LE16, nreq <= 16 ? 1 : 0);
 		KidCtx<P> kc;
-		kc.row = (Lds<uint32_t>)stage; kc.rot = 0; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
+		kc.R = (uint32_t)(uintptr_t)stage; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: the record, LHeap::prefetch) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);
@@ -1479,13 +1509,14 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			else {
 				if (!seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
 				uint32_t nm = ne & (MULTI ? member_mask(cr) : 2u << cr);
+				if (list_full<P>(nx, lcap)) { ovf = true; nm = 0; }
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;
 					P cl, cu;
 					kid(j, cl, cu);
 					nxw += (uint32_t)(cu - cl + 1);
-					list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap, ovf);
+					list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap);
 				}
 				s++;
 				bool swapped = false;
@@ -1677,8 +1708,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 template <typename P>
 __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uint64_t n, uint64_t seed, unsigned long long *checksum) {
 	__shared__ P s_base[BWB_BASE_ROWS * 16];
-	__shared__ u32x4 s_zero[8];
-	__shared__ u32x4 s_stage[LANE_BLOCK / 64][WAVE_LDS_BYTES / 16]; /* rows + exchange array */
+	__shared__ __align__(128) u32x4 s_zero[8];
+	__shared__ __align__(128) u32x4 s_stage[LANE_BLOCK / 64][WAVE_LDS_BYTES / 16]; /* rows + exchange array (rows 128-byte aligned: RowRef) */
 	if (threadIdx.x < 32) ((Lds<uint32_t>)&s_zero[0])[threadIdx.x] = 0u;
 	load_base<P>(s_base, ix);
 	const uint64_t nl = (uint64_t)gridDim.x * LANE_BLOCK;
@@ -1696,16 +1727,15 @@ __global__ __launch_bounds__(LANE_BLOCK) void k_rank_bench_lane(DevIndex ix, uin
 		wave_gather<P>(ix.buckets, pi, 0, stage, lane);
 		uint32_t rel[16];
 		const bool own = pi.blkL != NONE32;
-		const Lds<u32x4> row = own ? stage + lane * 8 : zero_row;
-		const int rot = own ? (lane >> 1) & 7 : 0;
+		const RowRef row = own ? row_ref(stage, (uint32_t)lane) : (uint32_t)(uintptr_t)zero_row;
 		{
 			SideBits bl;
-			side_read(row, rot, pi.offL, bl);
+			side_read(row, pi.offL, bl);
 			sub_pops16(bl.planes, bl.n, rel);
 			const uint32_t md[4] = { bl.mid.x, bl.mid.y, bl.mid.z, bl.mid.w };
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
-				const u32x4 c4 = row[(s + rot) & 7];
+				const u32x4 c4 = *row_slice(row, (uint32_t)s << 4);
 				rel[2 * s] += c4.x + (md[s] & 255u); rel[2 * s + 1] += c4.y + ((md[s] >> 8) & 255u);
 				rel[8 + 2 * s] += c4.z + ((md[s] >> 16) & 255u); rel[8 + 2 * s + 1] += c4.w + (md[s] >> 24);
 			}

@@ -231,6 +231,7 @@ def instrument(asm_path, kernels):
         init += "\ts_load_dwordx2 s[4:5], s[0:1], 0x%x\n\ts_waitcnt lgkmcnt(0)\n\tv_writelane_b32 v%d, s4, 0\n\tv_writelane_b32 v%d, s5, 1\n" % (0, vptr, vptr)
         first_ins = next(k for k in range(start + 1, end) if INSTR.match(lines[k]))
         inserts[first_ins].append(init)
+        init_at = len(inserts[first_ins]) - 1
         for b in blocks:
             if b.counter is None:
                 continue
@@ -260,7 +261,7 @@ def instrument(asm_path, kernels):
         explicit = [a for a in args if "offset" in a and not a.get("value_kind", "").startswith("hidden")]
         stats_off = int(explicit[-1]["offset"])
         init = init.replace("s[0:1], 0x0", "s[0:1], 0x%x" % stats_off)
-        inserts[first_ins][-1] = init
+        inserts[first_ins][init_at] = init
         dump = "\ts_mov_b64 exec, -1\n\tv_readlane_b32 s2, v%d, 0\n\tv_readlane_b32 s3, v%d, 1\n\ts_nop 3\n" % (vptr, vptr)
         dump += "\ts_add_u32 s2, s2, %d\n\ts_addc_u32 s3, s3, 0\n" % (BBPROF_BYTE_OFF + counter_base * 8)
         dump += "\tv_mbcnt_lo_u32_b32 v2, -1, 0\n\tv_mbcnt_hi_u32_b32 v2, -1, v2\n\tv_lshlrev_b32_e32 v2, 3, v2\n\tv_mov_b32_e32 v1, 0\n"
@@ -301,6 +302,7 @@ def build(flags, kernels):
         subprocess.run(s, cwd=d, shell=True, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     os.makedirs(os.path.dirname(OUT_LIB), exist_ok=True)
     run(["cp", os.path.join(d, "lib.so"), OUT_LIB])
+    run(["cp", asm, OUT_LIB[:-3] + ".s"])  # (for `listing`)
     json.dump(m, open(OUT_MAP, "w"))
     print("bbprof: wrote", OUT_LIB, "and", OUT_MAP)
 
@@ -363,7 +365,7 @@ def report(counts_path, map_path):
     for name, K in m["kernels"].items():
         blocks = K["blocks"]
         entry_counter = next(b["counter"] for b in blocks if b["counter"] is not None)
-        waves = counts[entry_counter]
+        waves = counts[entry_counter] or max(counts[b["counter"]] for b in blocks if b["counter"] is not None and not b["succ"]) if any(counts[b["counter"]] for b in blocks if b["counter"] is not None) else 0
         if not waves:
             continue
         # wave iterations = executions of the loop header: the block with the largest count whose label exists
@@ -426,7 +428,46 @@ def report(counts_path, map_path):
                   b["classes"].get("salu", 0) + b["classes"].get("branch", 0), b["classes"].get("lds", 0), b["classes"].get("vmem", 0), ["%d:%d" % (l, k) for f, l, k in top]))
 
 
+def listing(counts_path, asm_path, map_path, kern_sub, min_ratio):
+    """the instrumented assembly of one kernel, every counted block headed by its executions per wave iteration (gcov style)"""
+    m = json.load(open(map_path))
+    last = None
+    for ln in open(counts_path):
+        if ln.strip():
+            last = json.loads(ln)
+    counts = last["counters"]
+    name = next(k for k in m["kernels"] if kern_sub in k)
+    K = m["kernels"][name]
+    iters = (last.get("wave_iterations_search") if "kl_search" in name else 0) or max(counts[b["counter"]] for b in K["blocks"] if b["counter"] is not None)
+    vbase, cbase = K["vgpr_base"], K["counter_base"]
+    lines = open(asm_path).read().split("\n")
+    start = next(k for k, ln in enumerate(lines) if ln.startswith(name + ":"))
+    end = next(k for k in range(start, len(lines)) if lines[k].startswith(".Lfunc_end"))
+    out, show, loc, skip = [], True, "", 0
+    k = start
+    while k < end:
+        ln = lines[k]
+        mm = re.match(r"\s+v_readlane_b32 %s, v(\d+), (\d+)" % TEMP_SREG, ln)
+        if mm and int(mm.group(1)) >= vbase:
+            c = counts[cbase + (int(mm.group(1)) - vbase) * 64 + int(mm.group(2))]
+            show = c / iters >= min_ratio
+            if show:
+                out.append("### x%.3f per wave iteration (%d)" % (c / iters, c))
+            k += 6
+            continue
+        mm = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", ln)
+        if mm:
+            loc = "%s:%s" % (os.path.basename(m["files"].get(mm.group(1), mm.group(1))), mm.group(2))
+        elif show and (INSTR.match(ln) or LABEL.match(ln)):
+            out.append("%-90s ; %s" % (ln.split(";")[0].rstrip()[:90], loc) if INSTR.match(ln) else ln.split(";")[0])
+        k += 1
+    print("\n".join(out))
+
+
 def main():
+    if len(sys.argv) >= 2 and sys.argv[1] == "listing":  # listing counts.json instrumented.s <kernel-substring> [min executions per iteration]
+        listing(sys.argv[2], sys.argv[3], OUT_MAP, sys.argv[4], float(sys.argv[5]) if len(sys.argv) > 5 else 0.05)
+        return 0
     if len(sys.argv) < 2 or sys.argv[1] not in ("build", "report"):
         print(__doc__)
         return 2
