@@ -1191,50 +1191,47 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 		STAMP(0);
 		/* ---- A: pick the SA interval of this iteration ---- */
-		if (!active) { /* idle lanes only help with the cooperative rank below */ }
-		else if (!exact_mode) {
-			if (h.num_entries == 0 || h.num_entries > kp.max_entries) finish = true; /* :293,299 */
-			else {
-				const int bk = h.best(nb);
-				h.switch_cache(bk);
+		/* (Flat on purpose: with 64 reads per wave every path below is taken by some lane in nearly every iteration - tools/bbprof.py counts
+		 * 0.99 executions per wave iteration for all of them - so a nest of branches buys nothing and costs, per level, the scalar mask
+		 * bookkeeping and the copies of every value the branches merge: rounds 3-4 had four levels here.) */
+		const bool ex = active && exact_mode;      /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
+		const bool popping = active && !exact_mode;
+		const bool can_pop = popping && !(h.num_entries == 0 || h.num_entries > kp.max_entries); /* :293,299 */
+		if (can_pop) {
+			h.switch_cache(h.best(nb));
 #ifdef BWB_HIST
-				h_mirror = h.top_valid;
+			h_mirror = h.top_valid;
 #endif
-				h.pop(e, ld_cnt, pf_top, pf_hdr, pf_free); /* heap_pop :594-610: the top of the best bucket from its register mirror; what it uncovers is fetched now, under the gather */
-				is_group = (e.sa & 3u) == (uint32_t)STATE_GROUP;
-				/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the
-				 * group's last child, which happens in the next iteration, once the children are in place */
-				if (!is_group) r_pop++;
-				/* :309 (the reference pops that child, then stops).  aln_entry_t.score is an 8-bit field (align.h:104): what the reference compares is
-				 * the score modulo 256 - the same number unless the parameters allow scores above 255 */
-				if ((e_score & 255) > rd_best_score + kp.mm_score) { finish = true; if (is_group) r_pop++; }
-				else {
-					from_pop = true;
-					widx = (int)(e.f & 255u);
-					if (is_group) { /* the children are those of the parent's O_alphabet call (:382-383) */
-						h.num_entries++;
-						need_rank = true; iL = e.L; iU = e.U; alpha = MULTI;
-					} else if (widx > 0) {
-						need_rank = true; iL = e.L; iU = e.U;
-						/* an entry with no difference left goes to the exact tail (exact counts); any other one is expanded
-						 * with O_alphabet (:345,382) */
-						alpha = MULTI && (rd_max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0;
-					}
-				}
-			}
-		} else { /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
-			widx = r + 1;
-			if (s == curT - 1) { iL = cL; iU = cU; }
-			else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous step */
+			h.pop(e, ld_cnt, pf_top, pf_hdr, pf_free); /* heap_pop :594-610: the top of the best bucket from its register mirror; what it uncovers is fetched now, under the gather */
+		}
+		{
+			/* a deletion group is not an entry of the reference's heap: the pop that the reference makes here is that of the group's last
+			 * child, which happens in the next iteration, once the children are in place */
+			const bool grp = can_pop && (e.sa & 3u) == (uint32_t)STATE_GROUP;
+			/* :309 (the reference pops that child, then stops).  aln_entry_t.score is an 8-bit field (align.h:104): what the reference compares is
+			 * the score modulo 256 - the same number unless the parameters allow scores above 255 */
+			const bool over = can_pop && (e_score & 255) > rd_best_score + kp.mm_score;
+			finish = popping && (!can_pop || over);
+			r_pop += (can_pop && (!grp || over)) ? 1u : 0u;
+			from_pop = can_pop && !over;
+			is_group = grp && !over;                   /* the children are those of the parent's O_alphabet call (:382-383) */
+			h.num_entries += is_group ? 1 : 0;
+			widx = ex ? r + 1 : (int)(e.f & 255u);
+			need_rank = ex || (from_pop && (is_group || widx > 0));
+			/* an entry with no difference left goes to the exact tail (exact counts); any other one is expanded with O_alphabet (:345,382) */
+			alpha = MULTI && from_pop && (is_group || (rd_max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0);
+			iL = e.L; iU = e.U;                        /* (the popped entry's interval - and, in an exact tail, the tail of the current list: cL / cU) */
+		}
+		if (ex && s != curT - 1) {
+			if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous step */
 			else { /* (only the iteration after a resume: waited for inside the branch, see LHeap::pop) */
 				const Intv<P> v = (lbase + (cursel ? lcap : 0))[s]; iL = v.L; iU = v.U;
 				asm volatile("" :: "v"(iL), "v"(iU));
 			}
-			need_rank = true;
-			/* the interval of the step's NEXT iteration, when it is one of the list in memory (not its tail, which is in registers): fetched
-			 * now, under this iteration's gather (round 3 fetched it at the end of the iteration and used it at the start of the next) */
-			if (s + 1 < curT - 1) nxi = (lbase + (cursel ? lcap : 0))[s + 1];
 		}
+		/* the interval of the step's NEXT iteration, when it is one of the list in memory (not its tail, which is in registers): fetched
+		 * now, under this iteration's gather (round 3 fetched it at the end of the iteration and used it at the start of the next) */
+		if (ex && s + 1 < curT - 1) nxi = (lbase + (cursel ? lcap : 0))[s + 1];
 		h.prefetch(pf_top, pf_hdr); /* (the lanes have met again: see prefetch128) */
 
 #ifdef BWB_HIST
@@ -1329,142 +1326,150 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				h.top_valid = true; h.sec_valid = !WIDE && n >= 2; /* (n == 1 cannot happen: a single deletion child is stored as itself) */
 				h.cst = st0 + (uint32_t)n; h.mark(e_score);
 			}
-		} else if (from_pop) {
-			const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
-			const int e_alen = (int)((e.sa >> 2) & 255u);
-			const int diff_left = rd_max_diff - e_mm - e_go - e_ge;
-			const int diff_left_seed = kp.max_diff_seed - e_mm - e_go - e_ge;
-			const int seed_index = e_i - (rd_len - kp.seed_length);
-			bool pruned = diff_left < 0;                                                                  /* :313 */
-			if (!pruned && e_i > 0 && diff_left < (int)(wd & 127u)) pruned = true;                        /* :317 */
-			if (!pruned && seed_index > 0 && diff_left_seed < (int)(ws & 127u)) pruned = true;            /* :326 */
+		}
+		/* (the four things a popped entry can be are siblings, not a nest: see section A) */
+		const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
+		const int e_alen = (int)((e.sa >> 2) & 255u);
+		const int diff_left = rd_max_diff - e_mm - e_go - e_ge;
+		const int diff_left_seed = kp.max_diff_seed - e_mm - e_go - e_ge;
+		const int seed_index = e_i - (rd_len - kp.seed_length);
+		const bool pruned = diff_left < 0                                                          /* :313 */
+		                    || (e_i > 0 && diff_left < (int)(wd & 127u))                            /* :317 */
+		                    || (seed_index > 0 && diff_left_seed < (int)(ws & 127u));               /* :326 */
+		const bool live = from_pop && !is_group && !pruned;
+		const bool do_hit = live && e_i == 0, do_tail = live && e_i != 0 && diff_left == 0, do_expand = live && e_i != 0 && diff_left != 0;
 #ifdef BWB_HIST
-			HIST(H_PRUNED, pruned); HIST(H_HIT, !pruned && e_i == 0); HIST(H_EXACT_START, !pruned && e_i != 0 && diff_left == 0);
-			HIST(H_EXPAND, !pruned && e_i != 0 && diff_left != 0);
-			HIST(H_EXP_SAME_W1, !pruned && e_i != 0 && diff_left != 0 && hsame_ && hw_ == 1); HIST(H_EXP_SAME_W2_4, !pruned && e_i != 0 && diff_left != 0 && hsame_ && hw_ >= 2 && hw_ <= 4);
+		HIST(H_PRUNED, from_pop && !is_group && pruned); HIST(H_HIT, do_hit); HIST(H_EXACT_START, do_tail);
+		HIST(H_EXPAND, do_expand);
+		HIST(H_EXP_SAME_W1, do_expand && hsame_ && hw_ == 1); HIST(H_EXP_SAME_W2_4, do_expand && hsame_ && hw_ >= 2 && hw_ <= 4);
 #endif
-			if (!pruned) {
-				if (e_i == 0) { /* hit :331-344 */
-					if (n_alns == 0) {
-						SET_BEST_SCORE(e_score);
-						const int bd = e_mm + e_go + e_ge;
-						SET_MAX_DIFF((bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1);
-					}
-					if (e_score == rd_best_score) { num_best += (int)(uint32_t)(e.U - e.L + 1); add_aln(e.L, e.U, e_score, e_alen); }
-					else if (num_best > kp.max_best) finish = true;
-					else add_aln(e.L, e.U, e_score, e_alen);
-				} else if (diff_left == 0) { /* exact tail :345-375: its first step uses the children just computed */
-					cL = e.L; cU = e.U; curT = 1; cursel = false; s = 0; r = e_i - 1;
-					nx.T = 0; nxw = 0;
-					exact_mode = true;
-					exact_step = true;
-				} else {
-					STAMP(8);
-					/* ---- expansion :377-504 ---- */
-					r_vis_a += nvis;
-					bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
-					if (e_i - 1 > 0) {
-						const int d1 = wd & 255u, d2 = (wd >> 8) & 255u;
-						if ((diff_left - 1) < (d2 & 127)) allow_diff = false;
-						else if ((d1 & 127) == diff_left - 1 && (d2 & 127) == diff_left - 1 && (d1 & 128)) allow_mm = false;
-					}
-					if (seed_index - 1 > 0) {
-						const int d1 = ws & 255u, d2 = (ws >> 8) & 255u;
-						if ((diff_left_seed - 1) < (d2 & 127)) allow_diff = false;
-						else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
-					}
-					const int tmp = e_go + e_ge;
-					if ((e_i - 1 < kp.no_indel_length + tmp) || ((rd_len - (e_i - 1)) < kp.no_indel_length + tmp)) allow_indels = false;
-					if (e_go >= kp.max_gapo && e_ge >= kp.max_gape) allow_indels = false;
-					if (e_go >= kp.max_gapo) allow_open = false;
-					if (e_ge >= kp.max_gape) allow_extend = false;
-					const bool gap_open = e_state == STATE_M;
-					const int sc0 = e_score;
-					const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
-					const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
-					const bool mm_ok = allow_diff && allow_mm;
-					const uint32_t mem = cr > 3 ? 0u : (MULTI ? member_mask(cr) : 2u << cr);
-					/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
-					const uint32_t delm = del_ok ? ne : 0u;
-					const uint32_t mgrp = mm_ok ? ne : (ne & mem);
-					const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
-					const int nDel = __popc(delm), nIns = ins_ok ? 1 : 0, nX = __popc(mism), n0 = __popc(matchm);
-					const int nGc = nIns + nDel;            /* gap entries the reference pushes: what is counted */
-					const int nG = nIns + (nDel ? 1 : 0);   /* gap entries stored: the deletions as one group (STATE_GROUP) */
-					r_push += nGc + nX + n0;
+		if (do_hit) { /* hit :331-344 */
+			if (n_alns == 0) {
+				SET_BEST_SCORE(e_score);
+				const int bd = e_mm + e_go + e_ge;
+				SET_MAX_DIFF((bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1);
+			}
+			if (e_score == rd_best_score) { num_best += (int)(uint32_t)(e.U - e.L + 1); add_aln(e.L, e.U, e_score, e_alen); }
+			else if (num_best > kp.max_best) finish = true;
+			else add_aln(e.L, e.U, e_score, e_alen);
+		}
+		{ /* exact tail :345-375: its first step uses the children just computed (cL / cU are e.L / e.U already) */
+			curT = do_tail ? 1 : curT; cursel = do_tail ? false : cursel; s = do_tail ? 0 : s; r = do_tail ? e_i - 1 : r;
+			nx.T = do_tail ? 0 : nx.T; nxw = do_tail ? 0u : nxw;
+			exact_mode = exact_mode || do_tail;
+			exact_step = exact_step || do_tail;
+		}
+		if (do_expand) {
+			STAMP(8);
+			/* ---- expansion :377-504 ---- */
+			r_vis_a += nvis;
+			bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
+			if (e_i - 1 > 0) {
+				const int d1 = wd & 255u, d2 = (wd >> 8) & 255u;
+				if ((diff_left - 1) < (d2 & 127)) allow_diff = false;
+				else if ((d1 & 127) == diff_left - 1 && (d2 & 127) == diff_left - 1 && (d1 & 128)) allow_mm = false;
+			}
+			if (seed_index - 1 > 0) {
+				const int d1 = ws & 255u, d2 = (ws >> 8) & 255u;
+				if ((diff_left_seed - 1) < (d2 & 127)) allow_diff = false;
+				else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
+			}
+			const int tmp = e_go + e_ge;
+			if ((e_i - 1 < kp.no_indel_length + tmp) || ((rd_len - (e_i - 1)) < kp.no_indel_length + tmp)) allow_indels = false;
+			if (e_go >= kp.max_gapo && e_ge >= kp.max_gape) allow_indels = false;
+			if (e_go >= kp.max_gapo) allow_open = false;
+			if (e_ge >= kp.max_gape) allow_extend = false;
+			const bool gap_open = e_state == STATE_M;
+			const int sc0 = e_score;
+			const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
+			const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
+			const bool mm_ok = allow_diff && allow_mm;
+			const uint32_t mem = cr > 3 ? 0u : (MULTI ? member_mask(cr) : 2u << cr);
+			/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
+			const uint32_t delm = del_ok ? ne : 0u;
+			const uint32_t mgrp = mm_ok ? ne : (ne & mem);
+			const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
+			const int nDel = __popc(delm), nIns = ins_ok ? 1 : 0, nX = __popc(mism), n0 = __popc(matchm);
+			const int nGc = nIns + nDel;            /* gap entries the reference pushes: what is counted */
+			const int nG = nIns + (nDel ? 1 : 0);   /* gap entries stored: the deletions as one group (STATE_GROUP) */
+			r_push += nGc + nX + n0;
 #ifdef BWB_HIST
-					{ const int nne = __popc(ne);
-					  HIST(H_NE0, nne == 0); HIST(H_NE1, nne == 1); HIST(H_NE2, nne == 2); HIST(H_NE3_4, nne == 3 || nne == 4); HIST(H_NE5_8, nne >= 5 && nne <= 8); HIST(H_NE9, nne >= 9);
-					  HIST(H_DEL_OK, del_ok); HIST(H_MM_OK, mm_ok); HIST(H_INS_OK, ins_ok);
-					  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nGc; hl_mis += nX; hl_match += n0; }
+			{ const int nne = __popc(ne);
+			  HIST(H_NE0, nne == 0); HIST(H_NE1, nne == 1); HIST(H_NE2, nne == 2); HIST(H_NE3_4, nne == 3 || nne == 4); HIST(H_NE5_8, nne >= 5 && nne <= 8); HIST(H_NE9, nne >= 9);
+			  HIST(H_DEL_OK, del_ok); HIST(H_MM_OK, mm_ok); HIST(H_INS_OK, ins_ok);
+			  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nGc; hl_mis += nX; hl_match += n0; }
 #endif
-					/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
-					const int tX = kp.mm_score == 0 ? 0 : 1, tG = wG == 0 ? 0 : (wG == 1 ? 1 : 2);
-					const int k0 = n0 + (tX == 0 ? nX : 0) + (tG == 0 ? nG : 0);
-					const int k1 = (tX == 1 ? nX : 0) + (tG == 1 ? nG : 0);
-					const int k2 = tG == 2 ? nG : 0;
-					STAMP(9);
-					const uint32_t cst_old = h.cst;
-					uint32_t st0 = h.reserve(cst_old, k0, ovf, xs);
-					const uint32_t stX = h.stX, vGo = h.stGo, vGe = h.stGe, stG = wG == 2 ? vGo : vGe;
-					uint32_t st1 = h.reserve(stX, k1, ovf, xs);
-					uint32_t st2 = h.reserve(stG, k2, ovf, xs);
-					STAMP(10);
-					if (!ovf) {
-						/* child entry templates */
-						const uint32_t alen1 = (uint32_t)((e_alen + 1) & 255);
-						const uint32_t f_base = ((uint32_t)e_go << 16) | ((uint32_t)e_ge << 24);
-						const uint32_t f_match = (uint32_t)((e_i - 1) & 255) | ((uint32_t)e_mm << 8) | f_base;
-						const uint32_t f_mis = (uint32_t)((e_i - 1) & 255) | ((uint32_t)((e_mm + 1) & 255) << 8) | f_base;
-						const uint32_t f_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
-						const uint64_t eruns = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO;
-						uint64_t gruns_i, gruns_d; /* new run on open (start = aln_length, len 1); len+1 on extend */
-						if (gap_open) {
-							const int sh = 16 * (e_go & 3);
-							const uint64_t cleared = eruns & ~(0xFFFFull << sh);
-							gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
-							gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
-						} else gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
-						/* the slot last used on every target bucket (a state word is also the slot's index in the pool: chunk << 6 | fill) */
-						uint32_t s0 = st0, s1 = st1, s2 = st2;
-						auto emit = [&](uint32_t &sx, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
-							u32x4 w0, w1;
-							h.pack(L, U, f, sa, (uint32_t)runs, (uint32_t)(runs >> 32), w0, w1);
-							h.store_packed(++sx, w0, w1);
-							st_cnt++; /* (per lane and iteration; summed over the wave where the lanes meet again: wave_sum5) */
-						};
-						bool top_ok = false; /* does the register mirror hold the last entry pushed on bucket sc0? */
-						STAMP(11);
-						{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
-						   * holds the parent's interval (a single deletion child is stored as itself) */
-							uint32_t sg = tG == 0 ? s0 : (tG == 1 ? s1 : s2);
-							if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i);
-							const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
-							if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d); }
-							else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d);
-							if (tG == 0) s0 = sg; else if (tG == 1) s1 = sg; else s2 = sg;
-						}
-						STAMP(12);
-						const uint32_t sm = (uint32_t)STATE_M | (alen1 << 2);
-						if (kp.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
-							uint32_t sxm = tX == 1 ? s1 : s0;
-							uint32_t xm = mism;
-							while (xm) {
-								const int j = __ffs((int)xm) - 1;
-								xm &= xm - 1;
-								P cl, cu;
-								kid(j, cl, cu);
-								emit(sxm, cl, cu, f_mis, sm, eruns);
-							}
-							if (tX == 1) s1 = sxm; else s0 = sxm;
-							/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket being
-							 * popped): the register mirror is its only copy, its slot is reserved but never written.  The entry below it - the
-							 * match child before it, or with a single child what the pop uncovered, when nothing else went on top of that -
-							 * stays in the second mirror register. */
-							const u32x4 unc = h.tw; /* (what the pop uncovered: from the second mirror register, or on its way from memory) */
-							bool sec_ok = h.top_valid && k0 == 1;
-							u32x4 sec = unc;
-							uint32_t mm = matchm;
+			/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
+			const int tX = kp.mm_score == 0 ? 0 : 1, tG = wG == 0 ? 0 : (wG == 1 ? 1 : 2);
+			const int k0 = n0 + (tX == 0 ? nX : 0) + (tG == 0 ? nG : 0);
+			const int k1 = (tX == 1 ? nX : 0) + (tG == 1 ? nG : 0);
+			const int k2 = tG == 2 ? nG : 0;
+			STAMP(9);
+			const uint32_t cst_old = h.cst;
+			uint32_t st0 = h.reserve(cst_old, k0, ovf, xs);
+			const uint32_t stX = h.stX, vGo = h.stGo, vGe = h.stGe, stG = wG == 2 ? vGo : vGe;
+			uint32_t st1 = h.reserve(stX, k1, ovf, xs);
+			uint32_t st2 = h.reserve(stG, k2, ovf, xs);
+			STAMP(10);
+			if (!ovf) {
+				/* child entry templates */
+				const uint32_t alen1 = (uint32_t)((e_alen + 1) & 255);
+				const uint32_t f_base = ((uint32_t)e_go << 16) | ((uint32_t)e_ge << 24);
+				const uint32_t f_match = (uint32_t)((e_i - 1) & 255) | ((uint32_t)e_mm << 8) | f_base;
+				const uint32_t f_mis = (uint32_t)((e_i - 1) & 255) | ((uint32_t)((e_mm + 1) & 255) << 8) | f_base;
+				const uint32_t f_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
+				const uint64_t eruns = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO;
+				uint64_t gruns_i, gruns_d; /* new run on open (start = aln_length, len 1); len+1 on extend */
+				if (gap_open) {
+					const int sh = 16 * (e_go & 3);
+					const uint64_t cleared = eruns & ~(0xFFFFull << sh);
+					gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
+					gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
+				} else gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
+				/* the slot last used on every target bucket (a state word is also the slot's index in the pool: chunk << 6 | fill) */
+				uint32_t s0 = st0, s1 = st1, s2 = st2;
+				auto emit = [&](uint32_t &sx, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+					u32x4 w0, w1;
+					h.pack(L, U, f, sa, (uint32_t)runs, (uint32_t)(runs >> 32), w0, w1);
+					h.store_packed(++sx, w0, w1);
+					st_cnt++; /* (per lane and iteration; summed over the wave where the lanes meet again: wave_sum5) */
+				};
+				bool top_ok = false; /* does the register mirror hold the last entry pushed on bucket sc0? */
+				STAMP(11);
+				{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
+				   * holds the parent's interval (a single deletion child is stored as itself) */
+					uint32_t sg = tG == 0 ? s0 : (tG == 1 ? s1 : s2);
+					if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i);
+					const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
+					if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d); }
+					else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d);
+					if (tG == 0) s0 = sg; else if (tG == 1) s1 = sg; else s2 = sg;
+				}
+				STAMP(12);
+				const uint32_t sm = (uint32_t)STATE_M | (alen1 << 2);
+				if (kp.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
+					uint32_t sxm = tX == 1 ? s1 : s0;
+					uint32_t xm = mism;
+					while (xm) {
+						const int j = __ffs((int)xm) - 1;
+						xm &= xm - 1;
+						P cl, cu;
+						kid(j, cl, cu);
+						emit(sxm, cl, cu, f_mis, sm, eruns);
+					}
+					if (tX == 1) s1 = sxm; else s0 = sxm;
+					/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket being
+					 * popped): the register mirror is its only copy, its slot is reserved but never written.  The entry below it - the
+					 * match child before it, or with a single child what the pop uncovered, when nothing else went on top of that -
+					 * stays in the second mirror register. */
+					/* (peeled, round 5: the top child and the one below it are straight-line code, the loop only runs for a third match child
+					 * and beyond - no branch and no mirror copies inside a trip; slots are handed out in ascending code order all the same) */
+					if (matchm) {
+						const int jt = 31 - __clz((int)matchm);
+						uint32_t mm = matchm & ~(1u << jt);
+						if (mm) {
+							const int j2 = 31 - __clz((int)mm);
+							mm &= ~(1u << j2);
 							while (mm) {
 								const int j = __ffs((int)mm) - 1;
 								mm &= mm - 1;
@@ -1472,27 +1477,35 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								kid(j, cl, cu);
 								u32x4 w0, w1;
 								h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1);
-								if (mm) { h.store_packed(++s0, w0, w1); st_cnt++; sec = w0; sec_ok = true; }
-								else { h.tw = w0; h.tw1 = w1; }
+								h.store_packed(++s0, w0, w1); st_cnt++;
 							}
-							if (matchm) { top_ok = true; if (!WIDE) { h.sw = sec; h.sec_valid = sec_ok; } }
-						} else { /* mm_score == 0: one bucket, interleaved in code order */
-							uint32_t am = mgrp;
-							while (am) {
-								const int j = __ffs((int)am) - 1;
-								am &= am - 1;
-								P cl, cu;
-								kid(j, cl, cu);
-								emit(s0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
-							}
-						}
-						STAMP(13);
-						h.num_entries += nGc + nX + n0;
-						if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; if (!top_ok) h.sec_valid = false; if (st0 != cst_old) h.cprev = cst_old; }
-						if (k1 > 0) { h.stX = st1 + (uint32_t)k1; h.mark(scX); }
-						if (k2 > 0) { const uint32_t v = st2 + (uint32_t)k2; if (wG == 2) h.stGo = v; else h.stGe = v; h.mark(scG); }
+							P cl, cu;
+							kid(j2, cl, cu);
+							u32x4 w0, w1;
+							h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1);
+							h.store_packed(++s0, w0, w1); st_cnt++;
+							if (!WIDE) { h.sw = w0; h.sec_valid = true; }
+						} else if (!WIDE) { h.sw = h.tw; h.sec_valid = h.top_valid && k0 == 1; } /* (what the pop uncovered: from the second mirror register, or on its way from memory) */
+						P cl, cu;
+						kid(jt, cl, cu);
+						h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, h.tw, h.tw1);
+						top_ok = true;
+					}
+				} else { /* mm_score == 0: one bucket, interleaved in code order */
+					uint32_t am = mgrp;
+					while (am) {
+						const int j = __ffs((int)am) - 1;
+						am &= am - 1;
+						P cl, cu;
+						kid(j, cl, cu);
+						emit(s0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
 					}
 				}
+				STAMP(13);
+				h.num_entries += nGc + nX + n0;
+				if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; if (!top_ok) h.sec_valid = false; if (st0 != cst_old) h.cprev = cst_old; }
+				if (k1 > 0) { h.stX = st1 + (uint32_t)k1; h.mark(scX); }
+				if (k2 > 0) { const uint32_t v = st2 + (uint32_t)k2; if (wG == 2) h.stGo = v; else h.stGe = v; h.mark(scG); }
 			}
 		}
 
@@ -1505,11 +1518,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (exact_step && need_rank) {
 			bool exact_done = false;
 			uint32_t lastW = 0; /* summed width of the list that the step just completed */
-			if (cr > 3) { curT = 0; exact_done = true; } /* N in the read: exact_match.c:84-87 */
-			else {
-				if (!seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
-				uint32_t nm = ne & (MULTI ? member_mask(cr) : 2u << cr);
-				if (list_full<P>(nx, lcap)) { ovf = true; nm = 0; }
+			{ /* (selects, not a nest: one divergent region - the appends - per step) */
+				const bool isN = cr > 3; /* N in the read: exact_match.c:84-87 */
+				if (!isN && !seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
+				uint32_t nm = isN ? 0u : (ne & (MULTI ? member_mask(cr) : 2u << cr));
+				if (!isN && list_full<P>(nx, lcap)) { ovf = true; nm = 0; }
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
 					const int j = __ffs((int)nm) - 1;
 					nm &= nm - 1;
@@ -1518,22 +1531,24 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					nxw += (uint32_t)(cu - cl + 1);
 					list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap);
 				}
-				s++;
-				bool swapped = false;
-				if (!ovf && s >= curT) {
-					swapped = true;
-					cursel = !cursel; curT = nx.T; cL = nx.tL; cU = nx.tU;
-					if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers, not from what this step has just stored) */
-					nx.T = 0; s = 0;
-					lastW = nxw; nxw = 0;
-					if (curT == 0) exact_done = true; /* :114 */
-					else { r--; if (r < (seeding ? rd_len - PRECALC_LEN : 0)) exact_done = true; }
-				}
+				s += isN ? 0 : 1;
+				const bool swap = !isN && !ovf && s >= curT;
+				/* the list's swap; an N ends the tail with an empty list (curT = 0) */
+				cursel = swap ? !cursel : cursel;
+				cL = swap ? nx.tL : cL; cU = swap ? nx.tU : cU;
+				const int newT = isN ? 0 : nx.T;
+				const bool first2 = swap && newT >= 2;
+				nxi.L = first2 ? nx.fL : nxi.L; nxi.U = first2 ? nx.fU : nxi.U; /* (the new list's first interval: from registers, not from what this step has just stored) */
+				curT = (swap || isN) ? newT : curT;
+				lastW = swap ? nxw : 0u;
+				nx.T = swap ? 0 : nx.T; s = swap ? 0 : s; nxw = swap ? 0u : nxw;
+				const bool more = swap && newT != 0; /* :114 */
+				r -= more ? 1 : 0;
+				exact_done = isN || (swap && (newT == 0 || r < (seeding ? rd_len - PRECALC_LEN : 0)));
 				/* the interval of the next iteration, when it is not the list's tail (which is in registers): within a step it is on its way
 				 * since the start of this iteration; the first interval of a NEW list was kept in registers by list_add (round 4's first
 				 * version loaded what this step had just stored: the wait for it, at the start of the next iteration, was 10 % of the loop) */
 				nxi_valid = !ovf && !exact_done && s != curT - 1;
-				(void)swapped;
 			}
 			STAMP(6);
 			if (exact_done && !ovf && seeding) {

@@ -172,6 +172,58 @@ def round4():
     run([REF_BIN, "align", "-n", "5", "-M", "52", "-O", "60", "-E", "30", tfa, hq, os.path.join(HERE, "himm_n5bigpen.aln")])
 
 
+def round5():
+    """Round 5.  (1) The reference's OWN test input, test_data/sim_chr21_N100.fastq (data: 100 wgsim reads of chr21; config C1 of
+    BASELINE.json names it), through the reference's parser, aligner and SAM writer on the toy index - real chr21 reads do not map to a
+    synthetic text, so the records are nearly all empty: a parser / plumbing fixture.  (2) Parameters beyond what round 4's library
+    accepted: more than four gap opens per alignment (-o 5: aln_entry_t's 256-byte path holds any number, align.h:100-119) and
+    penalties above 63 (heap buckets are exact scores, inexact_match.c:510-516,548-591)."""
+    import shutil
+    fa = os.path.join(HERE, "toy.fa")
+    tmp = tempfile.mkdtemp(prefix="bwb_golden_")
+    tfa = os.path.join(tmp, "toy.fa")
+    for ext in ("", ".bwt", ".ann"):
+        shutil.copy(fa + ext, tfa + ext)
+    src = "/root/reference/test_data/sim_chr21_N100.fastq"
+    cq = os.path.join(HERE, "sim_chr21_N100.fastq")
+    shutil.copy(src, cq)
+    os.chmod(cq, 0o644)
+    for name, flags in (("n0", ["-n", "0"]), ("n2", ["-n", "2"])):
+        run([REF_BIN, "align"] + flags + [tfa, cq, os.path.join(HERE, f"sim_chr21_N100_{name}.aln")])
+    run([REF_BIN, "aln2sam", tfa, cq, os.path.join(HERE, "sim_chr21_N100_n2.aln"), os.path.join(HERE, "sim_chr21_N100_n2.sam")])
+    hq = os.path.join(HERE, "himm.fq")  # (round 4's mismatch- and indel-rich reads)
+    # reads with 2..6 single-base deletions or insertions, 12+ bases apart, cut from A/C/G/T-only windows of the toy genome: their best
+    # alignments open that many gaps (bwb_synth puts at most one indel into a read)
+    import random
+    rng = random.Random(505)
+    seq = "".join(ln.strip() for ln in open(fa).read().split(">")[1].split("\n")[1:])
+    recs = []
+    while len(recs) < 36:
+        k = 2 + len(recs) % 5
+        start = rng.randrange(0, len(seq) - 130)
+        win = seq[start:start + 120]
+        if set(win) - set("ACGT"):
+            continue
+        pos = sorted(rng.sample(range(18, 96, 13), k))
+        out, dele = [], len(recs) % 2 == 0
+        for i, ch in enumerate(win):
+            if i in pos:
+                if dele:
+                    continue
+                out.append(ch + rng.choice("ACGT"))
+            else:
+                out.append(ch)
+        read = "".join(out)[:100]
+        if len(recs) % 3 == 2:  # reverse strand
+            read = read[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        recs.append(f"@gap{len(recs)}_{k}{'del' if dele else 'ins'}\n{read}\n+\n{'2' * len(read)}\n")
+    gq = os.path.join(HERE, "gapo.fq")
+    open(gq, "w").write("".join(recs))
+    run([REF_BIN, "align", "-n", "6", "-o", "6", "-e", "6", "-m", "200000", tfa, gq, os.path.join(HERE, "gapo_o6.aln")])
+    run([REF_BIN, "align", "-n", "5", "-o", "5", "-e", "2", tfa, gq, os.path.join(HERE, "gapo_o5.aln")])
+    run([REF_BIN, "align", "-n", "3", "-M", "80", "-O", "90", "-E", "70", tfa, hq, os.path.join(HERE, "himm_M80.aln")])
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--extras":
         return extras()
@@ -254,5 +306,8 @@ def main():
     print("golden vectors written to", HERE)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "round5":
+    round5()
+    sys.exit(0)
 if __name__ == "__main__":
     main()

@@ -279,6 +279,57 @@ def test_random_parameter_sweep(mid_ctx, oracle):
         check(ctx, oracle, idx, flags, seqs, lens)
 
 
+def fuzz_case(rng, d, fa, tag):
+    """one case of tools/fuzz_parity.py's generator: flags, reads of one or two interleaved lengths (short reads inherit D_seed)"""
+    ln = rng.choice([24, 36, 50, 76, 100, 100, 125, 150, 200])
+    seqs, lens = synth_reads(fa, str(d / f"fz{tag}.fq"), rng.choice([300, 800, 1500]), ln, rng.randrange(10000),
+                             sub=rng.choice([0.5, 1.0, 2.0, 4.0]), indel=rng.choice([0.0, 1.0, 5.0]), npct=rng.choice([0.0, 1.0, 10.0]))
+    if rng.random() < 0.5:
+        s2, l2 = synth_reads(fa, str(d / f"fz{tag}b.fq"), rng.choice([100, 400]), rng.choice([20, 28, 33, 64, 100]), rng.randrange(10000), sub=2.0, indel=2.0, npct=2.0)
+        w = max(seqs.shape[1], s2.shape[1])
+        allseq = np.full((len(lens) + len(l2), w), 4, dtype=np.uint8)
+        allseq[:len(lens), :seqs.shape[1]] = seqs
+        allseq[len(lens):, :s2.shape[1]] = s2
+        order = np.random.default_rng(rng.randrange(1 << 30)).permutation(len(allseq))
+        seqs, lens = allseq[order], np.concatenate([lens, l2])[order]
+    flags = ["-n", str(rng.choice([0, 1, 2, 3, 3, 4])), "-o", str(rng.choice([0, 1, 1, 2, 3])), "-e", str(rng.choice([0, 2, 6])),
+             "-l", str(rng.choice([0, 16, 32, 32, 60])), "-k", str(rng.choice([0, 1, 2, 3])), "-M", str(rng.choice([1, 3, 3, 5])),
+             "-O", str(rng.choice([3, 11, 11])), "-E", str(rng.choice([1, 4, 4])), "-m", str(rng.choice([200, 5000, 3000000]))]
+    if rng.random() < 0.2:
+        flags.append("-S")
+    if rng.random() < 0.2:
+        flags.append("-P")
+    return flags, seqs, lens
+
+
+@pytest.mark.parametrize("env,seed,cases", [({}, 5001, 28), ({"BWB_SLICE_ITERS": "90"}, 5002, 12)])
+def test_fuzz_sweep_of_parameters_read_lengths_and_error_rates(mid, oracle, monkeypatch, env, seed, cases):
+    """40 seeded cases of tools/fuzz_parity.py's generator inside the GPU suite: random -n/-o/-e/-l/-k/-M/-O/-E/-m, -S, -P,
+    read lengths 24..200 with a second length interleaved, substitution / indel / N rates - 28 cases in one launch each, 12 with every
+    wave parked after 90 loop iterations (every read parked and resumed dozens of times).  Bytes, visits, pops and pushes equal to the
+    oracle's (serial reference: fresh_dseed = 0)."""
+    import random
+    d, fa = mid
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = bw.Context(fa + ".bwt")
+    idx = oracle.load_index(fa + ".bwt")
+    rng = random.Random(seed)
+    done = 0
+    try:
+        for c in range(cases):
+            flags, seqs, lens = fuzz_case(rng, d, fa, f"{seed}_{c}")
+            try:
+                bw.params(flags)
+                check(ctx, oracle, idx, flags, seqs, lens)
+                done += 1
+            except bw.BwbError as e:  # a refused parameter combination is loud, not wrong
+                assert "supported" in str(e) or "must be" in str(e), (flags, str(e))
+    finally:
+        ctx.close()
+    assert done >= cases - 2
+
+
 def test_short_reads_inherit_the_last_longer_reads_dseed(mid_ctx, oracle):
     """Reads <= seed_length mixed with longer ones: D_seed of a short read = that of the last longer read before it (the serial
     reference's single buffer, inexact_match.c:35,62-65); in one batch, and streamed in small batches with the carried read."""

@@ -228,6 +228,22 @@ def test_cli_wgsim_shaped_fastq(toy_dir, golden):
 
 
 @pytest.mark.gpu
+def test_cli_on_the_references_own_test_fastq(toy_dir, golden):
+    """the reference's test_data/sim_chr21_N100.fastq itself (config C1's literal input: 100 wgsim reads of chr21) through `align` with the
+    CLI default -n 0 and with -n 2, and through `aln2sam`, on the toy index: the reference's .aln and .sam bytes (real chr21 reads do not
+    map to the synthetic text - nearly every record is empty -, so this pins the parser, the record writer and the unmapped-read SAM lines)"""
+    fq = os.path.join(golden, "sim_chr21_N100.fastq")
+    for name, flags in (("n0", []), ("n2", ["-n", "2"])):  # (no flag at all = the reference's default, -n 0: align.c:26)
+        aln = toy_dir / f"chr21_{name}.aln"
+        log = run([bw.HOST_BIN, "align"] + flags + [str(toy_dir / "toy.fa"), fq, str(aln)])
+        assert "Processed 100 reads" in log
+        assert open(aln, "rb").read() == open(os.path.join(golden, f"sim_chr21_N100_{name}.aln"), "rb").read()
+    sam = toy_dir / "chr21_n2.sam"
+    run([bw.HOST_BIN, "aln2sam", str(toy_dir / "toy.fa"), fq, str(toy_dir / "chr21_n2.aln"), str(sam)])
+    assert open(sam).read() == open(os.path.join(golden, "sim_chr21_N100_n2.sam")).read()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("chunk", ["1000000", "7"])
 def test_cli_short_reads_match_serial_reference(toy_dir, golden, chunk):
     """the CLI on short.fq, in one chunk and in chunks of 7 reads (the D_seed source of a chunk's first short reads is carried over)"""
@@ -309,7 +325,7 @@ def _fastq2reads_model(path):
     return out
 
 
-@pytest.mark.parametrize("fq", ["wgsim100.fq", "ragged.fq", "short.fq"])
+@pytest.mark.parametrize("fq", ["wgsim100.fq", "ragged.fq", "short.fq", "sim_chr21_N100.fastq", "gapo.fq"])
 def test_fastq_reader_on_cpu(built, golden, tmp_path, fq):
     """host/reads.c without a GPU: names (wgsim style, blanks), codes (lower case, N), qualities, '+name' lines, blank lines and
     a missing final newline, against a record-by-record restatement of the reference's reader."""
@@ -323,7 +339,7 @@ def test_fastq_reader_on_cpu(built, golden, tmp_path, fq):
         assert ["".join(map(str, seqs[i, :lens[i]])) for i in range(len(lens))] == [g[1] for g in got]
 
 
-@pytest.mark.parametrize("fq,chunk", [("ragged.fq", 7), ("wgsim100.fq", 1), ("short.fq", 1000), ("toy.fq", 64)])
+@pytest.mark.parametrize("fq,chunk", [("ragged.fq", 7), ("wgsim100.fq", 1), ("short.fq", 1000), ("toy.fq", 64), ("sim_chr21_N100.fastq", 9)])
 def test_streaming_fastq_reader_equals_the_whole_file_reader(built, golden, tmp_path, fq, chunk):
     """`align` takes the FASTQ in chunks (host/reads.c: fq_next_chunk, the same record scanner): whatever the chunk size, the reads and
     their codes are those of fastq2reads, and the padding beyond a read's length is code 4."""

@@ -101,3 +101,17 @@ def test_scores_above_255_match_reference(oracle, golden, tmp_path):
             pairs, = struct.unpack_from("<i", data, pos + 4 + 16 + 16)
             pos += 4 + 16 + 16 + 4 + 4 * pairs
     assert top > 255
+
+
+ROUND5_FIXTURES = [("sim_chr21_N100.fastq", "sim_chr21_N100_n0.aln", ["-n", "0"]), ("sim_chr21_N100.fastq", "sim_chr21_N100_n2.aln", ["-n", "2"]),
+                   ("gapo.fq", "gapo_o6.aln", ["-n", "6", "-o", "6", "-e", "6", "-m", "200000"]), ("gapo.fq", "gapo_o5.aln", ["-n", "5", "-o", "5", "-e", "2"]),
+                   ("himm.fq", "himm_M80.aln", ["-n", "3", "-M", "80", "-O", "90", "-E", "70"])]
+
+
+@pytest.mark.parametrize("fq,aln,flags", ROUND5_FIXTURES)
+def test_round5_fixtures_match_reference(oracle, golden, tmp_path, fq, aln, flags):
+    """the reference's own test input (test_data/sim_chr21_N100.fastq: config C1) on the toy index; alignments with up to six gap opens
+    (gapo.fq: reads with 2..6 single-base indels); penalties above 63 (990 heap buckets)"""
+    out = str(tmp_path / "o.aln")
+    oracle.align_fastq(os.path.join(golden, "toy.fa.bwt"), os.path.join(golden, fq), out, oracle.params(flags))
+    assert open(out, "rb").read() == open(os.path.join(golden, aln), "rb").read()
