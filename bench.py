@@ -212,7 +212,7 @@ def main():
     # `ref_layout_GBs` prices the same visits at the reference layout's 192 B: a rate for comparison, not a fraction.
     vis_calcd = st.visits_calc_d
     vis_search = visits - vis_calcd
-    esz = 32 if p.max_gapo > 1 else 16
+    esz = 32 if (p.max_gapo > 1 or max(p.mm_score, p.gapo_score, p.gape_score) > 63) else 16
     def kernel(vis, ms, launches, bkt, extra_dev=0):
         sec = ms * 1e-3
         dev = bkt * DEV_BYTES_PER_BUCKET + extra_dev

@@ -455,7 +455,7 @@ static int check_params(const bwb_params *p, int *nb_out) {
 	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
 	if (p->seed_length < 0 || p->seed_length > 255) return fail(BWB_E_ARG, "seed_length must be in [0,255]");
 	if (p->mm_score < 0 || p->gapo_score < 0 || p->gape_score < 0) return fail(BWB_E_ARG, "negative penalties are not supported");
-	if (p->mm_score > 63 || p->gapo_score > 63 || p->gape_score > 63) return fail(BWB_E_ARG, "penalties (-M, -O, -E) above 63 are not supported on the GPU path");
+	if (p->mm_score > 255 || p->gapo_score > 255 || p->gape_score > 255) return fail(BWB_E_ARG, "penalties (-M, -O, -E) above 255 are not supported on the GPU path");
 	const int nb = (p->max_diff + 1) * p->mm_score + (p->max_gapo + 1) * p->gapo_score + (p->max_gape + 1) * p->gape_score; /* heap_init :513 */
 	if (nb < 1 || nb > 1024) return fail(BWB_E_ARG, "score range (heap buckets = (n+1) M + (o+1) O + (e+1) E) must be in [1,1024]");
 	if (p->max_entries < 1) return fail(BWB_E_ARG, "max_entries must be positive");
@@ -491,7 +491,9 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	if (s.uploaded) HIPCHK(hipEventSynchronize(s.ev_up.e)); /* its previous H2D copy has left the pinned staging buffers */
 	/* every slot in flight runs under the same parameters (they are launch arguments) */
 	if (c->have_params && memcmp(&c->p, p, sizeof(*p)) != 0 && (any_in_flight(c) || c->parked)) { rc = bwb_hip_flush(c); if (rc) return rc; }
-	const bool wide = p->max_gapo > 1;
+	/* 32-byte heap entries: more than one gap run per path - and penalties above 63, whose buckets can lie beyond the 64-bucket window of
+	 * the non-empty buckets: only these kernels carry the code for that (LHeap::far) */
+	const bool wide = p->max_gapo > 1 || p->mm_score > 63 || p->gapo_score > 63 || p->gape_score > 63;
 	if (c->cls[0].ready && wide != c->wide && c->parked) { rc = bwb_hip_flush(c); if (rc) return rc; }
 	c->p = *p; c->have_params = true;
 	c->kp = KParams{ p->max_diff, p->max_gapo, p->max_gape, p->max_entries, p->mm_score, p->gapo_score, p->gape_score,

@@ -679,10 +679,20 @@ template <typename P, bool WIDE> struct LHeap {
 		stGo = (side_of(pGo) == 2 && cb + pGo < nbk) ? bstate[cb + pGo] : NONE32;
 		stGe = (side_of(pGe) == 3 && cb + pGe < nbk) ? bstate[cb + pGe] : NONE32;
 	}
-	__device__ __forceinline__ void mark(int s) { neW |= 1ull << (s - cb); }
-	__device__ __forceinline__ void unmark(int s) { neW &= ~(1ull << (s - cb)); }
-	__device__ __forceinline__ int best(int nb) const {
-		return neW ? cb + __ffsll((long long)neW) - 1 : nb;
+	/* Penalties above 63 (WIDE instantiation only: the host routes such parameters to the 32-byte-entry kernels, whatever -o is): a child's
+	 * bucket can lie beyond the window.  Such a bucket is simply not marked - its state is in a side register or in memory - and the window
+	 * is topped up from the bucket states in memory whenever it moves (switch_cache, after the side registers have been written back); when
+	 * the window is empty the states beyond it are scanned (best).  `far` is wave-uniform; the 16-byte-entry kernels do not have the code. */
+	bool far;
+	__device__ __forceinline__ void mark(int s) { if (!WIDE || !far || s - cb < 64) neW |= 1ull << (s - cb); }
+	__device__ __forceinline__ void unmark(int s) { if (!WIDE || !far || s - cb < 64) neW &= ~(1ull << (s - cb)); }
+	__device__ __forceinline__ int best(int nb) {
+		if (neW) return cb + __ffsll((long long)neW) - 1;
+		if (WIDE && far) { /* (rare: nothing within 63 of the cached bucket) */
+			side_flush();
+			for (int k = cb + 64; k < nbk; k++) if (bstate[k] != NONE32) return k;
+		}
+		return nb;
 	}
 	__device__ __forceinline__ void switch_cache(int s) {
 		if (s == cb) return;
@@ -693,8 +703,11 @@ template <typename P, bool WIDE> struct LHeap {
 		const bool have = d == pX || d == pGo || d == pGe;
 		const uint32_t vX = stX, vGo = stGo, vGe = stGe; /* (values first: a conditional between two members is a conditional between two addresses, and keeps the whole struct in memory) */
 		const uint32_t fwd = d == pX ? vX : (d == pGo ? vGo : vGe);
-		neW >>= d; /* (s > cb: the cached bucket is empty and nothing lies below it) */
+		neW = (WIDE && far && d >= 64) ? 0ull : neW >> d; /* (s > cb: the cached bucket is empty and nothing lies below it) */
 		cb = s; cst = have ? fwd : bstate[s];
+		if (WIDE && far) { /* buckets that have come into the window's range: their states are in memory (side_flush above) */
+			for (int j = d >= 64 ? 0 : 64 - d; j < 64 && s + j < nbk; j++) if (j == 0 || bstate[s + j] != NONE32) neW |= 1ull << j;
+		}
 		side_load();
 		top_valid = false; sec_valid = false; cprev = 0;
 	}
@@ -969,6 +982,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow; h.nslots = sc.nslots;
 	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.pX = kp.mm_score; h.pGo = kp.gapo_score; h.pGe = kp.gape_score; h.nbk = nb;
+	h.far = WIDE && (kp.mm_score > 63 || kp.gapo_score > 63 || kp.gape_score > 63);
 	h.fhead = NONE32;
 	h.reset();
 
@@ -1012,6 +1026,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	uint32_t n_bkt = 0, n_rec = 0; /* wave-uniform: buckets fetched, records loaded (heap entries stored / fetched: s_cnt) */
 	uint32_t acc_st = 0, acc_ld = 0; /* per lane, for the whole launch: heap entries stored / fetched (summed over the wave once, at the end) */
 	bool parked = false;
+	uint32_t age = 0; /* slices this lane's read has been parked at the end of (0: started in this launch) */
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -1037,6 +1052,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		nxi.L = p64(a5.x, a5.y); nxi.U = p64(a5.z, a5.w);
 		e.f = a6.x; e.sa = a6.y; e.runsLo = a6.z; e.runsHi = a6.w;
 		h.pused = a7.x; h.xhead = a7.y;
+		age = a7.z;
 		h.neW = ((uint64_t)a8.y << 32) | a8.x; h.cb = (int)a8.z; h.cst = a8.w;
 		h.side_load(); /* (the side buckets' states went to memory when the read was parked) */
 		h.num_entries = (int)a9.x; r_vis_s = a9.y; r_vis_a = a9.z; r_pop = a9.w;
@@ -1049,6 +1065,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	} else {
 		for (int k = 0; k < nb; k++) h.bstate[k] = NONE32;
 	}
+#ifdef BWB_AGE_PRIO
+	/* A wave that resumes a read which has already been through BWB_AGE_PRIO slices - the heavy tail: one read in a hundred takes 10-50 x the
+	 * median's iterations and decides when its slot can be used again and how long the stream's last launch lasts - issues ahead of its
+	 * SIMD's other waves for the rest of the launch: the same work, the long chains first. */
+	if (__any(active && age >= (uint32_t)BWB_AGE_PRIO)) __builtin_amdgcn_s_setprio(2);
+#endif
 
 	for (;;) {
 		STAMP(7);
@@ -1143,7 +1165,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				mysave[14] = make_uint4(lo(nx.fL), hi(nx.fL), lo(nx.fU), hi(nx.fU));
 				mysave[5] = make_uint4(lo(nxi.L), hi(nxi.L), lo(nxi.U), hi(nxi.U));
 				mysave[6] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-				mysave[7] = make_uint4(h.pused, h.xhead, 0u, 0u);
+				mysave[7] = make_uint4(h.pused, h.xhead, age + 1u, 0u);
 				mysave[8] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), (uint32_t)h.cb, h.cst);
 				mysave[9] = make_uint4((uint32_t)h.num_entries, r_vis_s, r_vis_a, r_pop);
 				mysave[10] = make_uint4(r_push, 0u, 0u, 0u);
@@ -1661,6 +1683,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_need_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			h.bstate[h.cb] = NONE32;
+			if (WIDE && h.far) { for (int k = 0; k < nb; k++) h.bstate[k] = NONE32; h.neW = 0; } /* (buckets beyond the window may be in use) */
 			while (h.neW) { const int k = h.best(nb); h.bstate[k] = NONE32; h.unmark(k); }
 			active = false;
 		}

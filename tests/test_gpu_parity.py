@@ -121,16 +121,22 @@ def test_scores_above_255_match_reference(toy_ctx, golden):
 
 def test_penalty_and_score_range_limits(toy_ctx, oracle, golden):
     """Score ranges beyond round 2's 128 heap buckets work (bucket-state rows are sized by the range: here (n+1) M + 2 O + 7 E = 320
-    buckets) and equal the oracle; a penalty above 63 is refused (the non-empty buckets are a 64-bit window above the current one)."""
+    buckets) and equal the oracle.  Penalties above 63 (round 5): a child's bucket can lie beyond the 64-bucket window of the non-empty
+    buckets - the 32-byte-entry kernels handle that (LHeap::far) - with the REAL reference's bytes for -M 80 -O 90 -E 70 (990 buckets)
+    and the oracle's for mixed sizes; above 255, or more than 1 024 buckets, is refused loudly."""
     seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "toy.fq"), max_reads=300))
-    flags = ["-n", "3", "-M", "40", "-O", "45", "-E", "10"]
-    off, alns = toy_ctx.align(bw.params(flags), seqs, lens)
     idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"))
-    want, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags))
-    assert bw.aln_bytes(off, alns) == want
-    st = toy_ctx.stats()
-    assert st.heap_pops == ost.heap_pops and st.heap_pushes == ost.heap_pushes
-    for bad in (["-M", "64"], ["-O", "70"], ["-E", "100"], ["-n", "100", "-M", "60"]):
+    for flags in (["-n", "3", "-M", "40", "-O", "45", "-E", "10"], ["-n", "3", "-M", "70", "-O", "65", "-E", "5"], ["-n", "2", "-M", "3", "-O", "200", "-E", "100", "-e", "3"],
+                  ["-n", "4", "-M", "130", "-O", "11", "-E", "64", "-e", "2"], ["-n", "1", "-M", "255", "-O", "255", "-E", "2", "-o", "0"]):
+        off, alns = toy_ctx.align(bw.params(flags), seqs, lens)
+        want, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags))
+        assert bw.aln_bytes(off, alns) == want, flags
+        st = toy_ctx.stats()
+        assert st.heap_pops == ost.heap_pops and st.heap_pushes == ost.heap_pushes, flags
+    hs, hl = bw.encode_reads(bw.read_fastq(os.path.join(golden, "himm.fq")))
+    off, alns = toy_ctx.align(bw.params(["-n", "3", "-M", "80", "-O", "90", "-E", "70"]), hs, hl)
+    assert bw.aln_bytes(off, alns) == open(os.path.join(golden, "himm_M80.aln"), "rb").read()
+    for bad in (["-M", "256"], ["-O", "300"], ["-E", "1000"], ["-n", "100", "-M", "60"], ["-n", "3", "-M", "200", "-O", "200", "-E", "200"]):
         with pytest.raises(bw.BwbError):
             toy_ctx.align(bw.params(bad), seqs[:1], lens[:1])
     toy_ctx.align(bw.params(["-n", "2"]), seqs[:50], lens[:50])  # the context is still usable
