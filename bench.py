@@ -21,6 +21,7 @@ the GPU).  See DESIGN.md "Measurement".
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import time
@@ -346,28 +347,79 @@ def end_to_end(ctx, p, batch, ns, B, value):
 
 
 def cli_end_to_end(a, fa, fq, flags, value, ctx, bw):
-    """What a user of the product sees: the wall time of the C CLI - `bwbble align` from process start to exit - on this rank's whole
-    FASTQ shard (the read pool), .bwt file -> host -> HBM, FASTQ parsing, alignment, .aln writing included.  The CLI overlaps the
-    three (host/align_gpu.c: loader threads, streamed context creation, reader thread, ordered writer).  The Python context keeps
-    its index but gives its heap chunk pool back first (BWB_POOL_GB-sized pools for both would not fit the CLI's own)."""
-    out_aln = fq + ".cli.aln"
+    """What a user of the product sees: the wall time of the C CLI - `bwbble align` from process start to exit - .bwt file -> host -> HBM,
+    FASTQ parsing, alignment, .aln writing included.  The CLI overlaps all of it (host/align_gpu.c: loader threads, streamed context
+    creation, parallel FASTQ scanner, one worker per GPU that also serialises its chunks' records, ordered writer).  Three runs:
+    this rank's read pool (10 M reads) with the bench's flags; `long_stream`: the pool two and a half times over (>= 25 M reads: the one
+    draining launch at the end of a stream and the index load weigh less, as in a real run); `n0`: the pool with the CLI's default -n 0,
+    where the host stages matter most (2.3 M+ reads/s per GPU).  `host_pipeline`: the two host stages alone, on this box's cores.
+    The Python context gives its memory back first (the CLI's context sizes its heap chunk pool from what is free)."""
     try:
-        ctx.close()  # the CLI's context sizes its pool from what is free
+        ctx.close()
     except Exception:
         pass
-    t0 = time.perf_counter()
-    r = subprocess.run([bw.HOST_BIN, "align"] + flags + [fa, fq, out_aln], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    dt = time.perf_counter() - t0
-    if r.returncode != 0:
-        return {"error": (r.stdout + r.stderr)[-400:]}
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("GPUs:")]
-    n = a.pool
-    res = {"value": round(n / dt, 1), "unit": "reads/s", "reads": n, "wall_s": round(dt, 2), "of_value": round(n / dt / value, 4),
-           "command": "bwbble align " + " ".join(flags) + " <fasta> <fastq> <out.aln>", "cli_summary": line[-1] if line else ""}
+
+    def run_cli(fl, fastq, n_reads, keep=None):
+        out_aln = fastq + ".cli.aln"
+        t0 = time.perf_counter()
+        r = subprocess.run([bw.HOST_BIN, "align"] + fl + [fa, fastq, out_aln], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("GPUs:")]
+        res = {"value": round(n_reads / dt, 1), "unit": "reads/s", "reads": n_reads, "wall_s": round(dt, 2),
+               "command": "bwbble align " + " ".join(fl) + " <fasta> <fastq> <out.aln>", "cli_summary": line[-1] if line else ""}
+        if keep:
+            os.replace(out_aln, keep)
+        else:
+            try:
+                os.remove(out_aln)
+            except OSError:
+                pass
+        return res
+
+    kept = fq + ".kept.aln"
+    res = run_cli(flags, fq, a.pool, keep=kept)
+    if "error" in res:
+        return res
+    res["of_value"] = round(res["value"] / value, 4)
+    # the two host stages of the pipeline on their own (`bwbble hostbench`: reads.c's scanner + encoder, aln_io.c's chunk serialiser)
     try:
-        os.remove(out_aln)
+        hb = subprocess.run([bw.HOST_BIN, "hostbench", fq, kept], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+        hj = json.loads(hb.stdout.strip().splitlines()[-1])
+        res["host_pipeline"] = {"parse_reads_per_s": hj["parse_reads_per_s"], "write_records_per_s": hj.get("write_records_per_s"), "reads": hj["parse_reads"],
+                                "cores": os.cpu_count(), "what": "FASTQ record scan (parallel, verified against the sequential scan) + base encoding; .aln record serialisation of the run above"}
+    except Exception as e:  # noqa: BLE001
+        res["host_pipeline"] = {"error": str(e)[-200:]}
+    try:
+        os.remove(kept)
     except OSError:
         pass
+    if a.config == "C3":
+        # >= 25 M reads: the pool's FASTQ two and a half times over (the same reads again: only the length of the stream matters here)
+        long_fq = fq + ".long.fq"
+        with open(long_fq, "wb") as g:
+            for rep in range(3):
+                with open(fq, "rb") as f:
+                    if rep < 2:
+                        shutil.copyfileobj(f, g, 1 << 24)
+                    else:  # half of the file, cut at a record boundary
+                        half = os.path.getsize(fq) // 2
+                        data = f.read(half)
+                        cut = data.rfind(b"\n@")  # (this generator's qualities never start a line with '@')
+                        g.write(data[:cut + 1])
+                        n_half = data[:cut + 1].count(b"\n") // 4
+        n_long = 2 * a.pool + n_half
+        lr = run_cli(flags, long_fq, n_long)
+        if "error" not in lr:
+            lr["of_value"] = round(lr["value"] / value, 4)
+        res["long_stream"] = lr
+        try:
+            os.remove(long_fq)
+        except OSError:
+            pass
+        n0 = run_cli(["-n", "0"], fq, a.pool)
+        res["n0"] = n0
     return res
 
 

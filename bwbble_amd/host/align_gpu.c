@@ -27,13 +27,14 @@ static double wall(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &t
 
 void set_default_aln_params(aln_params_t *p) { bwb_default_params(p); } /* align.c:22-38 */
 
-/* One chunk of the FASTQ on its way through the pipeline: parsed by the reader thread, aligned by one of the GPU workers, written by
- * the main thread - in file order. */
+/* One chunk of the FASTQ on its way through the pipeline: parsed by the reader thread (several scanner threads: reads.c), aligned by one
+ * of the GPU workers - which also turns the hits into the chunk's .aln bytes (aln_io.c: alns2alnf_buf) -, written by the main thread in
+ * file order with one write per chunk. */
 typedef struct chunk {
 	size_t idx;
 	fq_chunk_t fq;                 /* the reads (freed once the chunk is uploaded) */
 	uint8_t *carry; uint32_t carry_len; /* the last read before the chunk that computes a D_seed (NULL: none), a copy */
-	uint64_t *aln_off; bwb_aln *alns; uint32_t n; /* host copy of the chunk's result */
+	unsigned char *buf; size_t buf_len; uint32_t n; /* the chunk's .aln records, serialised by the worker that received its hits */
 	int ready;
 	struct chunk *next;            /* production order */
 } chunk_t;
@@ -111,13 +112,8 @@ static void *reader_thread(void *arg) {
 static void retire(worker_t *w, bwb_hip_ctx *ctx, int slot, chunk_t *c) {
 	bwb_result r;
 	if (bwb_hip_slot_result(ctx, slot, &r)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->gpu, bwb_hip_last_error());
-	const uint32_t n = r.n_reads;
-	c->n = n;
-	c->aln_off = (uint64_t *)malloc(((size_t)n + 1) * 8);
-	memcpy(c->aln_off, r.aln_off, ((size_t)n + 1) * 8);
-	const uint64_t tot = r.aln_off[n];
-	c->alns = (bwb_aln *)malloc((tot ? tot : 1) * sizeof(bwb_aln));
-	memcpy(c->alns, r.alns, tot * sizeof(bwb_aln));
+	c->n = r.n_reads;
+	c->buf = alns2alnf_buf(r.alns, r.aln_off, r.n_reads, &c->buf_len); /* (with all cores; the library's result buffers stay valid until the slot is uploaded again) */
 	pthread_mutex_lock(&w->pp->mu);
 	c->ready = 1;
 	pthread_cond_broadcast(&w->pp->cv_done);
@@ -258,12 +254,11 @@ int align_reads_inexact_gpu_stream(bwt_t *BWT, const char *readsFname, aln_param
 		if (c) { pp.first = c->next; if (!pp.first) pp.last = NULL; }
 		pthread_mutex_unlock(&pp.mu);
 		if (!c) break;
-		for (uint32_t i = 0; i < c->n; i++)
-			alns2alnf_bin(c->alns + c->aln_off[i], c->aln_off[i + 1] - c->aln_off[i], alnFile);
+		if (c->buf_len && fwrite(c->buf, 1, c->buf_len, alnFile) != c->buf_len) bwb_die("align_reads_inexact: Cannot write to the ALN file: %s!", alnFname);
 		processed += c->n;
 		printf("Processed %zu reads. Elapsed: %.2f sec\n", processed, wall() - t0);
 		if (dbg) fprintf(stderr, "[bwb host] writer: chunk %zu written at +%.3f s\n", c->idx, wall() - t0);
-		free(c->aln_off); free(c->alns); free(c);
+		free(c->buf); free(c);
 		pthread_mutex_lock(&pp.mu);
 		pp.n_written++;
 		pthread_cond_broadcast(&pp.cv_space);

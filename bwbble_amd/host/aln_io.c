@@ -47,6 +47,66 @@ void alns2alnf_bin(const bwb_aln *alns, uint64_t n, FILE *f) {
 	}
 }
 
+/* The records of a whole chunk of reads as ONE byte buffer (round 5: built by the GPU worker that received the chunk's hits, with all
+ * cores, so that the ordered writer only write()s; per-read fwrites in the writer thread were what a stream of several GPUs queued
+ * behind).  Same bytes as alns2alnf_bin read by read.  Returns the malloc'ed buffer, *len = its length. */
+static inline size_t aln_rec_bytes(const bwb_aln *a) {
+	/* 36 bytes of fixed fields + the pair count + one pair per run of equal states in the path */
+	if (a->aln_length == 0) return 40;
+	unsigned char path[272];
+	const int alen = aln_path_bytes(a, path);
+	int pairs = 1;
+	for (int j = alen - 2; j >= 0; j--) pairs += path[j] != path[j + 1];
+	return 40 + 4 * (size_t)pairs;
+}
+static inline unsigned char *aln_rec_put(const bwb_aln *a, unsigned char *o) {
+	int32_t hdr[9];
+	unsigned char path[272];
+	const int nogap = a->gap_run[0] == 0xFFFFu && a->gap_run[1] == 0xFFFFu && a->gap_run[2] == 0xFFFFu && a->gap_run[3] == 0xFFFFu;
+	const int alen = nogap ? (int)a->aln_length : aln_path_bytes(a, path);
+	hdr[0] = a->score; memcpy(hdr + 1, &a->L, 8); memcpy(hdr + 3, &a->U, 8);
+	hdr[5] = a->num_mm; hdr[6] = a->num_gapo; hdr[7] = a->num_gape; hdr[8] = alen;
+	memcpy(o, hdr, 36); o += 36;
+	if (alen <= 0) { const int32_t z = 0; memcpy(o, &z, 4); return o + 4; }
+	if (nogap) { const int32_t v[2] = { 1, 0 | (alen << 2) }; memcpy(o, v, 8); return o + 8; } /* (all STATE_M: one pair) */
+	int32_t *pp = (int32_t *)o; /* (4-byte aligned: every field before it is) */
+	int pairs = 0, state = path[alen - 1];
+	uint16_t counter = 1;
+	for (int j = alen - 2; j >= 0; j--) {
+		if (state == path[j]) counter++;
+		else { pp[++pairs] = state | (counter << 2); state = path[j]; counter = 1; }
+	}
+	pp[++pairs] = state | (counter << 2);
+	pp[0] = pairs;
+	return o + 4 * ((size_t)pairs + 1);
+}
+unsigned char *alns2alnf_buf(const bwb_aln *alns, const uint64_t *aln_off, uint32_t n_reads, size_t *len) {
+	size_t *pos = (size_t *)malloc(((size_t)n_reads + 1) * sizeof(size_t));
+#pragma omp parallel for schedule(static)
+	for (long r = 0; r < (long)n_reads; r++) {
+		size_t b = 4;
+		for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; i++) {
+			const bwb_aln *a = &alns[i];
+			const int nogap = a->gap_run[0] == 0xFFFFu && a->gap_run[1] == 0xFFFFu && a->gap_run[2] == 0xFFFFu && a->gap_run[3] == 0xFFFFu;
+			b += (nogap && a->aln_length) ? 44 : aln_rec_bytes(a);
+		}
+		pos[r + 1] = b;
+	}
+	pos[0] = 0;
+	for (uint32_t r = 0; r < n_reads; r++) pos[r + 1] += pos[r];
+	unsigned char *buf = (unsigned char *)malloc(pos[n_reads] ? pos[n_reads] : 1);
+#pragma omp parallel for schedule(static)
+	for (long r = 0; r < (long)n_reads; r++) {
+		unsigned char *o = buf + pos[r];
+		const int32_t ne = (int32_t)(aln_off[r + 1] - aln_off[r]);
+		memcpy(o, &ne, 4); o += 4;
+		for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; i++) o = aln_rec_put(&alns[i], o);
+	}
+	*len = pos[n_reads];
+	free(pos);
+	return buf;
+}
+
 alns_batch_t *alnsf2alns_bin(const char *alnFname) {
 	FILE *f = fopen(alnFname, "rb");
 	if (!f) bwb_die("alnsf2alns: Cannot open ALN file: %s!", alnFname);

@@ -95,6 +95,7 @@ void fq_close(fq_stream *s);
 
 /* aln_io.c */
 void alns2alnf_bin(const bwb_aln *alns, uint64_t n, FILE *alnFile);    /* align.c:345-382, one read */
+unsigned char *alns2alnf_buf(const bwb_aln *alns, const uint64_t *aln_off, uint32_t n_reads, size_t *len); /* the same bytes for a chunk of reads, as one buffer */
 alns_batch_t *alnsf2alns_bin(const char *alnFname);                    /* align.c:430-483 */
 void free_alns_batch(alns_batch_t *b);
 int aln_path_bytes(const bwb_aln *a, unsigned char *path /* >= 272 bytes */); /* edit path from the gap runs; returns aln_length */

@@ -1,6 +1,8 @@
 /* main.c - `bwbble` command line, same commands and flags as the reference (mg-aligner/main.c:38-160),
  * plus -g <n_gpus> on align / aln2sam. */
+#define _GNU_SOURCE
 #include <getopt.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include "bwb_host.h"
@@ -124,14 +126,64 @@ int main(int argc, char *argv[]) {
 		store_bwt(B, argv[3]);
 		free_bwt(B);
 	} else if (strcmp(argv[1], "alncat") == 0) {
-		/* developer command (CPU only, used by the tests): .aln -> memory (alnsf2alns_bin) -> .aln (alns2alnf_bin) */
-		if (argc < 4) { printf("Usage: bwbble alncat <in_aln> <out_aln> \n"); exit(1); }
+		/* developer command (CPU only, used by the tests): .aln -> memory (alnsf2alns_bin) -> .aln (alns2alnf_bin read by read, or with a
+		 * fifth argument `buf` the chunk serialiser of `align`, alns2alnf_buf, in chunks of a few reads) */
+		if (argc < 4) { printf("Usage: bwbble alncat <in_aln> <out_aln> [buf [chunk_reads]]\n"); exit(1); }
 		alns_batch_t *b = alnsf2alns_bin(argv[2]);
 		FILE *f = fopen(argv[3], "wb");
 		if (!f) { perror(argv[3]); return 1; }
-		for (size_t r = 0; r < b->n_reads; r++) alns2alnf_bin(b->alns + b->aln_off[r], b->aln_off[r + 1] - b->aln_off[r], f);
+		if (argc >= 5) {
+			const size_t chunk = argc >= 6 ? (size_t)atol(argv[5]) : 1000;
+			for (size_t r0 = 0; r0 < b->n_reads; r0 += chunk) {
+				const size_t n = b->n_reads - r0 < chunk ? b->n_reads - r0 : chunk;
+				uint64_t *off = (uint64_t *)malloc((n + 1) * 8); /* (chunk-relative, like a slot's result) */
+				for (size_t k = 0; k <= n; k++) off[k] = b->aln_off[r0 + k] - b->aln_off[r0];
+				size_t len = 0;
+				unsigned char *buf = alns2alnf_buf(b->alns + b->aln_off[r0], off, (uint32_t)n, &len);
+				fwrite(buf, 1, len, f);
+				free(buf); free(off);
+			}
+		} else for (size_t r = 0; r < b->n_reads; r++) alns2alnf_bin(b->alns + b->aln_off[r], b->aln_off[r + 1] - b->aln_off[r], f);
 		fclose(f);
 		free_alns_batch(b);
+	} else if (strcmp(argv[1], "hostbench") == 0) {
+		/* developer command (CPU only; bench.py's host_pipeline keys): the two host stages of `align` on their own - the FASTQ reader
+		 * (parallel record scan + base encoding, reads.c) in chunks of BWB_CHUNK reads, and the chunk serialiser (aln_io.c) on an .aln file */
+		if (argc < 3) { printf("Usage: bwbble hostbench <reads_fastq> [<aln>]\n"); exit(1); }
+		struct timespec t0, t1;
+		const uint32_t chunk = getenv("BWB_CHUNK") ? (uint32_t)strtoul(getenv("BWB_CHUNK"), NULL, 10) : (1u << 21);
+		clock_gettime(CLOCK_MONOTONIC, &t0);
+		fq_stream *fs = fq_open(argv[2]);
+		fq_chunk_t ch;
+		uint64_t n = 0, cks = 0;
+		while (fq_next_chunk(fs, chunk, &ch)) { n += ch.n; cks += ch.seq[(size_t)(ch.n - 1) * ch.stride] + ch.len[0]; free(ch.seq); free(ch.len); }
+		fq_close(fs);
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+		printf("{\"parse_reads\": %llu, \"parse_s\": %.4f, \"parse_reads_per_s\": %.0f, \"checksum\": %llu", (unsigned long long)n, dt, n / (dt > 0 ? dt : 1), (unsigned long long)cks);
+		if (argc >= 4) {
+			alns_batch_t *b = alnsf2alns_bin(argv[3]);
+			double best = 1e30; size_t bytes = 0;
+			for (int rep = 0; rep < 3; rep++) {
+				clock_gettime(CLOCK_MONOTONIC, &t0);
+				bytes = 0;
+				for (size_t r0 = 0; r0 < b->n_reads; r0 += chunk) {
+					const size_t nn = b->n_reads - r0 < chunk ? b->n_reads - r0 : chunk;
+					uint64_t *off = (uint64_t *)malloc((nn + 1) * 8);
+					for (size_t k = 0; k <= nn; k++) off[k] = b->aln_off[r0 + k] - b->aln_off[r0];
+					size_t len = 0;
+					unsigned char *buf = alns2alnf_buf(b->alns + b->aln_off[r0], off, (uint32_t)nn, &len);
+					bytes += len;
+					free(buf); free(off);
+				}
+				clock_gettime(CLOCK_MONOTONIC, &t1);
+				dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+				if (dt < best) best = dt;
+			}
+			printf(", \"write_records\": %zu, \"write_bytes\": %zu, \"serialise_s\": %.4f, \"write_records_per_s\": %.0f", b->n_reads, bytes, best, b->n_reads / (best > 0 ? best : 1));
+			free_alns_batch(b);
+		}
+		printf("}\n");
 	} else {
 		printf("Error: Unknown command '%s'\n", argv[1]);
 		usage();

@@ -349,6 +349,46 @@ def test_streaming_fastq_reader_equals_the_whole_file_reader(built, golden, tmp_
     assert [ln.split("\t")[1] for ln in open(whole).read().split("\n")[:-1]] == open(parts).read().split("\n")[:-1]
 
 
+def _nasty_fastq(path, n=400, seed=9):
+    """a FASTQ that a boundary guesser can misread: quality lines that start with '@' or '+', '@' and '+' inside names and qualities,
+    '+name' separator lines, blank lines between records, lower-case bases, ragged lengths, no final newline"""
+    import random
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        ln = rng.choice([1, 2, 17, 36, 100, 100, 151])
+        seq = "".join(rng.choice("ACGTNacgt") for _ in range(ln))
+        if rng.random() < 0.2:
+            seq = "+" + seq[1:]  # (a base the reader encodes as N: after a quality line that starts with '@' the guess takes that line for a name)
+        q0 = rng.choice("@+I@+5")
+        qual = q0 + "".join(rng.choice("@+IJ5#") for _ in range(ln - 1))
+        name = f"r{i}" + rng.choice(["", " @x", " +y", "/1 len=+@"])
+        sep = "+" + (name if rng.random() < 0.3 else "")
+        out.append(f"@{name}\n{seq}\n{sep}\n{qual}\n" + ("\n" if rng.random() < 0.1 else ""))
+    text = "".join(out)
+    open(path, "w").write(text[:-1] if text.endswith("\n") else text)
+
+
+@pytest.mark.parametrize("region,threads,chunk", [("64", "3", 7), ("300", "7", 50), ("1000", "16", 1), ("4096", "5", 100000), ("1", "2", 33), ("100000000", "8", 13)])
+def test_parallel_fastq_scanner_finds_the_sequential_scanners_records(built, golden, tmp_path, monkeypatch, region, threads, chunk):
+    """host/reads.c (round 5): a region of the file is scanned by several threads that GUESS where their part's first record starts, and the
+    parts are only accepted where the reference's sequential scan (io.c:430-498) would have arrived at the same '@'.  With regions of a
+    few bytes to a few KB (BWB_FQ_REGION) every record is cut by part boundaries; on the golden files and on a FASTQ built to mislead the
+    guess the chunks must hold exactly fastq2reads' reads."""
+    nasty = tmp_path / "nasty.fq"
+    _nasty_fastq(str(nasty))
+    monkeypatch.setenv("BWB_FQ_REGION", region)
+    monkeypatch.setenv("BWB_FQ_THREADS", threads)
+    for fq in (os.path.join(golden, "wgsim100.fq"), os.path.join(golden, "ragged.fq"), os.path.join(golden, "sim_chr21_N100.fastq"), str(nasty)):
+        whole, parts = tmp_path / "whole.tsv", tmp_path / "parts.txt"
+        run([bw.HOST_BIN, "dumpreads", fq, str(whole)])
+        run([bw.HOST_BIN, "dumpreads", fq, str(parts), str(chunk)])
+        want = [ln.split("\t")[1] for ln in open(whole).read().split("\n")[:-1]]
+        assert open(parts).read().split("\n")[:-1] == want, fq
+        if fq == str(nasty):
+            assert want == [g[1] for g in _fastq2reads_model(fq)] and len(want) == 400
+
+
 def test_threaded_bwt_loader_reads_the_file_exactly(built, golden, tmp_path, monkeypatch):
     """host/bwt_io.c: the .bwt file read by several threads in units, blocks_ready monotone up to num_occ, the arrays (incl. the
     sampled SA) identical to the file's."""
@@ -421,3 +461,17 @@ def test_interleave_helper_runs_the_command_or_says_why_not():
     else:
         assert r.returncode == 125 and "ran" not in r.stdout
     assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln", "gapo_o5.aln", "himm_n5bigpen.aln", "sim_chr21_N100_n2.aln"])
+@pytest.mark.parametrize("chunk", ["1", "7", "100000"])
+def test_chunk_serialiser_writes_the_record_writers_bytes(built, golden, tmp_path, aln, chunk):
+    """host/aln_io.c (round 5): `align` turns a chunk's hits into ONE byte buffer in the GPU worker (alns2alnf_buf, all cores) and the
+    ordered writer only writes it; the bytes must be those of the record-by-record writer alns2alnf_bin (align.c:345-382) - all-match paths
+    (the fast path), gapped paths with several runs, empty records, scores above 255."""
+    one, buf = tmp_path / "one.aln", tmp_path / "buf.aln"
+    if aln == "gapo_o5.aln":  # (more than four gap runs per path: outside bwb_aln until the ABI holds eight runs)
+        pytest.skip("gapo_o5.aln has paths with five gap runs; bwb_aln holds four")
+    run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(one)])
+    run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(buf), "buf", chunk])
+    assert open(buf, "rb").read() == open(one, "rb").read()
