@@ -116,7 +116,11 @@ def main():
         if not os.path.exists(ok):
             n_rec = 1 if n_fwd <= 60_000_000 else 24
             subprocess.run([bw.SYNTH_BIN, "genome", fa, str(n_fwd), str(n_rec), str(max(4, n_fwd // 2400)), "21"], check=True)
-            subprocess.run([bw.HOST_BIN, "index", fa], check=True, stdout=subprocess.DEVNULL)
+            import resource
+            t_ix = time.time()
+            subprocess.run([bw.HOST_BIN, "index", fa], check=True, stdout=subprocess.DEVNULL)  # f3: the product's own index builder (host/index.c)
+            json.dump({"index_s": round(time.time() - t_ix, 1), "peak_rss_GB": round(resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6, 1),
+                       "bwt_bytes": os.path.getsize(fa + ".bwt"), "cores": os.cpu_count()}, open(fa + ".index_stats.json", "w"))
             if os.path.exists(fa + ".ref"):
                 os.remove(fa + ".ref")  # 2 bytes per forward character that nothing here reads
             open(ok, "w").write("ok\n")
@@ -256,7 +260,8 @@ def main():
                              "128-byte buckets actually fetched (an L-1/U pair in one bucket is fetched once) + heap entries stored and loaded + "
                              "per-position records; `achieved_ref_layout_GBs` prices the same visits at the reference layout's 192 B (SURVEY 8d): a rate, not a fraction"},
         "hits_batch0": int(off0[-1]), "rerun_reads": int(st.n_overflow_reads), "kernel_ms_of_step_ms": round(kern_ms / (dt * 1e3), 4),
-        "setup_s": {"genome_index_reads": round(t_build, 1), "index_to_hbm": round(t_ctx, 1)},
+        "setup_s": {"genome_index_reads": round(t_build, 1), "index_to_hbm": round(t_ctx, 1),
+                    "index": (json.load(open(fa + ".index_stats.json")) if os.path.exists(fa + ".index_stats.json") else None)},
     }
     if shard_check is not None:
         out["shard_sample_parity"] = shard_check
@@ -391,6 +396,31 @@ def cli_end_to_end(a, fa, fq, flags, value, ctx, bw):
                                 "cores": os.cpu_count(), "what": "FASTQ record scan (parallel, verified against the sequential scan) + base encoding; .aln record serialisation of the run above"}
     except Exception as e:  # noqa: BLE001
         res["host_pipeline"] = {"error": str(e)[-200:]}
+    # f1: `bwbble aln2sam` on the same records - SA(L) of every mapped read by the invPsi walk on the GPU (k_locate: up to 31
+    # dependent rank-block visits per row), MAPQ / CIGAR / text on the host's cores
+    try:
+        sam = fq + ".cli.sam"
+        t0 = time.perf_counter()
+        r = subprocess.run([bw.HOST_BIN, "aln2sam"] + (["-n", str(a.ndiff)] if a.ndiff else []) + [fa, fq, kept, sam], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            res["aln2sam"] = {"error": (r.stdout + r.stderr)[-300:]}
+        else:
+            ln = [x for x in r.stdout.splitlines() if x.startswith("SA lookups on the GPU:")]
+            f = ln[-1].split() if ln else []
+            rows, visits, kms = (int(f[6]), int(f[9]), float(f[11])) if len(f) > 11 else (0, 0, 0.0)
+            res["aln2sam"] = {"wall_s": round(dt, 2), "reads": a.pool, "reads_per_s": round(a.pool / dt, 1), "sam_bytes": os.path.getsize(sam),
+                              "k_locate": {"rows": rows, "visits": visits, "kernel_ms": kms, "Gvisits_per_s": round(visits / kms / 1e6, 2) if kms else 0.0,
+                                           "device_GBs": round(visits * DEV_BYTES_PER_BUCKET / kms / 1e6, 1) if kms else 0.0,
+                                           "device_frac": round(visits * DEV_BYTES_PER_BUCKET / kms / 1e6 / HBM_PEAK_GBS, 4) if kms else 0.0,
+                                           "note": "a chain of dependent visits per row (31 at most, SA samples every 32 rows): latency-bound by construction, the fraction says how much of it the rows in flight hide"},
+                              "command": "bwbble aln2sam <fasta> <fastq> <aln> <sam> (wall: .bwt + SA -> host -> HBM, .aln and FASTQ loaded, SA lookups, SAM text by all cores)"}
+        try:
+            os.remove(sam)
+        except OSError:
+            pass
+    except Exception as e:  # noqa: BLE001
+        res["aln2sam"] = {"error": str(e)[-200:]}
     try:
         os.remove(kept)
     except OSError:

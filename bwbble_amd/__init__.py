@@ -19,7 +19,7 @@ SYNTH_BIN = os.path.join(HERE, "bin", "bwb_synth")
 EXPORTS = [
     "bwb_hip_device_count", "bwb_hip_last_error", "bwb_default_params", "bwb_hip_ctx_create", "bwb_hip_ctx_destroy",
     "bwb_hip_align_batch", "bwb_hip_batch_upload", "bwb_hip_batch_run", "bwb_hip_batch_result", "bwb_hip_get_stats",
-    "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate",
+    "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate", "bwb_hip_locate_stats",
     "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush", "bwb_hip_abi_version", "bwb_hip_ctx_create_streamed", "bwb_hip_device_numa_node",
 ]
 ABI_VERSION = 2  # BWB_HIP_ABI_VERSION (include/bwbble_hip.h)
@@ -94,6 +94,7 @@ def lib():
         L.bwb_hip_flush.argtypes = [C.c_void_p]
         L.bwb_hip_set_sa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.bwb_hip_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.bwb_hip_locate_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -262,6 +263,12 @@ class Context:
         out = np.zeros(len(rows), dtype=np.uint64)
         _chk(lib().bwb_hip_locate(self._h, rows.ctypes.data, len(rows), out.ctypes.data))
         return out
+
+    def locate_stats(self):
+        """(rows, invPsi steps = rank-block visits, kernel ms) of the last locate()"""
+        n, st, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        _chk(lib().bwb_hip_locate_stats(self._h, C.byref(n), C.byref(st), C.byref(ms)))
+        return n.value, st.value, ms.value
 
 
 # -- formats ------------------------------------------------------------------------------------

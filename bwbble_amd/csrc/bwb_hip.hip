@@ -141,6 +141,7 @@ struct bwb_hip_ctx {
 	std::vector<PendingTime> pending;
 	std::vector<hipEvent_t> free_events;
 	uint32_t slice_iters = 0;           /* BWB_SLICE_ITERS: test knob, time-sliced launches */
+	double locate_ms = 0; uint64_t locate_steps = 0, locate_rows = 0; /* the last bwb_hip_locate call */
 	bool force_slices = false;          /* BWB_FORCE_SLICES: the one-batch API parks and resumes too (tests) */
 	bool dbg = false, dbg_iters = false;
 	bwb_stats stats{};
@@ -1161,10 +1162,31 @@ extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, ui
 	HIPCHK(dout.alloc(n * 8));
 	HIPCHK(hipMemcpyAsync(dr.p, rows, n * 8, hipMemcpyHostToDevice, c->stream));
 	const unsigned grid = (unsigned)std::min<size_t>((n + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK, (size_t)c->num_cu * 8);
-	hipLaunchKernelGGL(k_locate, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, c->d_SA.as<uint64_t>(), c->sa0_index, dr.as<uint64_t>(), (uint64_t)n, dout.as<uint64_t>());
+	hipEvent_t e0 = get_event(c), e1 = get_event(c);
+	if (!e0 || !e1) return fail(BWB_E_HIP, "hipEventCreate failed");
+	unsigned long long *steps = c->d_stats.as<unsigned long long>() + STAT_LOCATE_STEPS;
+	HIPCHK(hipMemsetAsync(steps, 0, 8, c->stream));
+	HIPCHK(hipEventRecord(e0, c->stream));
+	hipLaunchKernelGGL(k_locate, dim3(grid), dim3(BWB_BLOCK), 0, c->stream, c->ix, c->d_SA.as<uint64_t>(), c->sa0_index, dr.as<uint64_t>(), (uint64_t)n, dout.as<uint64_t>(), c->d_stats.as<unsigned long long>());
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(e1, c->stream));
 	HIPCHK(hipMemcpyAsync(out_pos, dout.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+	unsigned long long hsteps = 0;
+	HIPCHK(hipMemcpyAsync(&hsteps, steps, 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	c->free_events.push_back(e0); c->free_events.push_back(e1);
+	c->locate_ms = ms; c->locate_steps = hsteps; c->locate_rows = n;
+	return BWB_OK;
+}
+
+/* the last bwb_hip_locate call: rows, invPsi steps (= rank-block visits: one 128-byte bucket each) and the kernel's HIP-event time */
+extern "C" int bwb_hip_locate_stats(bwb_hip_ctx *c, uint64_t *rows, uint64_t *steps, double *kernel_ms) {
+	if (!c) return fail(BWB_E_ARG, "locate_stats: null context");
+	if (rows) *rows = c->locate_rows;
+	if (steps) *steps = c->locate_steps;
+	if (kernel_ms) *kernel_ms = c->locate_ms;
 	return BWB_OK;
 }
 

@@ -72,7 +72,7 @@ struct Work {
 enum { STAT_VIS_SINGLE = 0, STAT_VIS_ALPHA, STAT_POPS, STAT_PUSHES, STAT_ALNS, STAT_N, STAT_N_MAX, STAT_VIS_CALCD,
        STAT_BKT_SEARCH /* 128-byte buckets fetched by kl_search */, STAT_BKT_CALCD, STAT_PARKED /* reads parked at the end of a slice */,
        STAT_ENT_ST /* heap entries kl_search stored */, STAT_ENT_LD /* ... loaded */, STAT_REC_LD /* per-position records it loaded */,
-       STAT_WAVE_ITERS = 16, STAT_WAVE_ITERS_CALCD = 17, STAT_STAMPS = 24, STAT_HIST = 40 /* BWB_HIST diagnostic build */, STAT_BBPROF = 104 /* tools/bbprof.py: one 64-bit counter per basic block */,
+       STAT_WAVE_ITERS = 16, STAT_WAVE_ITERS_CALCD = 17, STAT_LOCATE_STEPS = 18 /* k_locate: invPsi steps */, STAT_STAMPS = 24, STAT_HIST = 40 /* BWB_HIST diagnostic build */, STAT_BBPROF = 104 /* tools/bbprof.py: one 64-bit counter per basic block */,
 #ifdef BWB_BBPROF
        STAT_WORDS = 104 + 2048 };
 #else
@@ -280,7 +280,7 @@ __global__ void k_dseed_inherit(Batch b, const uint32_t *src, uint32_t n) {
 }
 
 /* SA[row] by the invPsi walk (bwt.c:311-329): one octet per row */
-__global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_t *SA, uint64_t sa0_index, const uint64_t *rows, uint64_t n, uint64_t *out) {
+__global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_t *SA, uint64_t sa0_index, const uint64_t *rows, uint64_t n, uint64_t *out, unsigned long long *stats) {
 	__shared__ uint64_t s_base[BWB_BASE_ROWS * 16];
 	load_base<uint64_t>(s_base, ix);
 	const int lane = threadIdx.x & 63, ol = lane & 7;
@@ -305,6 +305,6 @@ __global__ __launch_bounds__(BWB_BLOCK) void k_locate(DevIndex ix, const uint64_
 			i = nxt;
 			j++;
 		}
-		if (ol == 0) out[q] = (SA[i >> 5] + j) % ix.length;
+		if (ol == 0) { out[q] = (SA[i >> 5] + j) % ix.length; if (j) atomicAdd(&stats[STAT_LOCATE_STEPS], (unsigned long long)j); } /* (j: invPsi steps = rank-block visits, the step through the sentinel row included) */
 	}
 }

@@ -406,6 +406,43 @@ __device__ __forceinline__ uint32_t grab_read(const Work &wk) {
 	return wk.worklist ? wk.worklist[w] : w;
 }
 
+/* Loads that are ISSUED AHEAD of the iteration's gather and land under the gather's wait, IN PLACE, for the lanes named by `mask`.  The
+ * destination register holds live values in the other lanes, so the compiler will not let an ordinary load inside a divergent branch write
+ * it: it loads into a scratch register and copies under the exec mask - and the copy waits for the load on the spot, which puts the memory
+ * round trip back in front of the gather.  Here the load is one statement in uniform control flow whose asm narrows the exec mask itself: to
+ * the compiler a plain read-modify-write of `dst`, which stays where it is.  THE RULE: the compiler does not know that the register is in
+ * flight - nothing may read it until a vmcnt(0) wait has been executed (kl_search: the gather's own wait, or the explicit one after it when
+ * no lane of the wave needed a rank).  tools/check_prefetch_regs.py verifies on the ISA of every build that no instruction touches these
+ * registers in between. */
+__device__ __forceinline__ void prefetch128(u32x4 &dst, const void *p, unsigned long long mask) {
+	unsigned long long sv;
+	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void prefetch64(u32x2 &dst, const void *p, unsigned long long mask) {
+	unsigned long long sv;
+	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx2 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
+}
+__device__ __forceinline__ void prefetch32(uint32_t &dst, const void *p, unsigned long long mask) {
+	unsigned long long sv;
+	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dword %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
+}
+
+/* an SA interval in the registers it is loaded into (16 bytes with 64-bit positions, 8 with 32-bit ones) */
+template <typename P> struct IntvRegs;
+template <> struct IntvRegs<uint64_t> {
+	typedef u32x4 W;
+	static __device__ __forceinline__ void fetch(W &d, const Intv<uint64_t> *p, unsigned long long m) { prefetch128(d, p, m); }
+	static __device__ __forceinline__ uint64_t lo(const W w) { return ((uint64_t)w.y << 32) | w.x; }
+	static __device__ __forceinline__ uint64_t hi(const W w) { return ((uint64_t)w.w << 32) | w.z; }
+};
+template <> struct IntvRegs<uint32_t> {
+	typedef u32x2 W;
+	static __device__ __forceinline__ void fetch(W &d, const Intv<uint32_t> *p, unsigned long long m) { prefetch64(d, p, m); }
+	static __device__ __forceinline__ uint32_t lo(const W w) { return w.x; }
+	static __device__ __forceinline__ uint32_t hi(const W w) { return w.y; }
+};
+
 /* ============================================================================================
  * k_calc_d (one read per lane)
  * ========================================================================================== */
@@ -430,7 +467,15 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 	bool active = false, done = false;
 	uint32_t rid = 0;
 	int len = 0, phase = 0, plen = 0, r = 0, z = 0, s = 0, curT = 0, cursel = 0;
-	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* the interval of the next iteration, when it comes from the list in memory */
+	Intv<P> nxi; nxi.L = nxi.U = 0; bool nxi_valid = false; /* the FIRST interval of the list a position has just completed (registers: ListW::fL / fU) */
+	/* The intervals of the current list that are in memory are read FOUR AT A TIME (round 5): one aligned 64-byte group (32 bytes with 32-bit
+	 * positions) per four iterations instead of a 16-byte load per iteration.  A scattered 16-byte load is a whole 64-byte request to the
+	 * memory fabric (tools/pmc_traffic.sh calibration), the L1 is swept by the gather between two iterations, and kl_calc_d runs at 84 % of
+	 * the bandwidth a streaming read reaches with its traffic 1.44 x its bucket bytes - 0.7 list requests per iteration were most of that
+	 * excess (profiles/r4_c3_pmc.json).  gI = the cached group, cg = its number (interval index >> 2), -1: none. */
+	typedef IntvRegs<P> IR;
+	typename IR::W g0 = {}, g1 = {}, g2 = {}, g3 = {};
+	int cg = -1;
 	int c = 4, cnext = 4; /* seq[r] and seq[r - 1]: loaded once per position, one position ahead (round 2 loaded seq[r] in every iteration) */
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
@@ -456,7 +501,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 					for (uint32_t m = 0; m < rec_count((uint32_t)len); m++) rz[m] = make_uint4(0u, 0u, 0u, m << 16);
 				}
 				c = len > 0 ? seq[len - 1] : 4; cnext = len > 1 ? seq[len - 2] : 4;
-				cL = 0; cU = last_row; curT = 1; nxi_valid = false;
+				cL = 0; cU = last_row; curT = 1; nxi_valid = false; cg = -1;
 				nx.T = 0;
 				active = len > 0;
 				if (!(kp.seed_length && len > kp.seed_length)) {
@@ -475,16 +520,30 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 		}
 		if (__all(done)) break;
 		P iL = 0, iU = 0;
+		/* (the cached group is only ever touched here and by the prefetch below, in straight-line code at the loop's top level: with its uses
+		 * inside the nest of branches the register allocator kept a second copy of it and moved one into the other while the prefetch was in
+		 * flight - tools/check_prefetch_regs.py, which the Makefile runs on every build) */
+		const int gq = s & 3;
+		const typename IR::W gw = gq == 0 ? g0 : (gq == 1 ? g1 : (gq == 2 ? g2 : g3));
 		if (active) {
 			if (c > 3 && phase == 0) cntN++;
 			if (c <= 3) {
 				if (s == curT - 1) { iL = cL; iU = cU; }
-				else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched ahead of the previous iteration's gather, or the new list's first interval (registers) */
+				else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* the new list's first interval (registers) */
+				else if ((s >> 2) == cg) { iL = IR::lo(gw); iU = IR::hi(gw); } /* from the group fetched ahead of an earlier iteration's gather */
 				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; asm volatile("" :: "v"(iL), "v"(iU)); } /* (never in the steady state: waited for inside the branch) */
-				/* the interval of the position's NEXT iteration, when it is one of the list in memory: fetched now, under this iteration's gather
-				 * (round 3 fetched it at the end of the iteration and used it at the start of the next: an exposed round trip per iteration) */
-				if (s + 1 < curT - 1) nxi = (lbase + cursel * cap)[s + 1];
 			}
+		}
+		{ /* the group of the interval of the position's NEXT iteration, when that is one of the list in memory and not in the cached group:
+		   * issued now, IN PLACE (prefetch128: nothing looks at g0..g3 before the gather's wait below), and landing under this iteration's
+		   * gather.  The cached group is not needed any more then: the next interval is the first of another group. */
+			const bool want = active && c <= 3 && s + 1 < curT - 1 && ((s + 1) >> 2) != cg;
+			const unsigned long long mw = __ballot(want);
+			/* (not under `if (mw)`: a branch around the in-place loads makes the compiler merge a loaded and a not-loaded version of the four
+			 * registers behind it - copies of registers that are in flight; with an empty mask the loads are no-ops) */
+			const Intv<P> *g = lbase + cursel * cap + ((s + 1) & ~3);
+			IR::fetch(g0, g, mw); IR::fetch(g1, g + 1, mw); IR::fetch(g2, g + 2, mw); IR::fetch(g3, g + 3, mw);
+			cg = want ? (s + 1) >> 2 : cg;
 		}
 		const bool need = active && c <= 3;
 		uint32_t nbk = 0;
@@ -513,7 +572,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 			cursel ^= 1;
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
 			if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers - list_add -, not from what this step has just stored) */
-			nx.T = 0; s = 0;
+			nx.T = 0; s = 0; cg = -1;
 			if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
 				cL = 0; cU = last_row; curT = 1; z++;
 				nm = (int32_t)(uint32_t)ix.length;
@@ -553,8 +612,8 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 				}
 			}
 		}
-		/* the interval of the next iteration, when it is not the list's tail (which is in registers): already in nxi (see above) */
-		nxi_valid = active && c <= 3 && s != curT - 1;
+		/* the interval of the next iteration: the list's tail and a new list's first interval are in registers, the others come from the group cache */
+		nxi_valid = active && c <= 3 && s == 0 && curT >= 2;
 	}
 	if (vis) { atomicAdd(&stats[STAT_VIS_SINGLE], vis); atomicAdd(&stats[STAT_VIS_CALCD], vis); }
 	if (lane == 0 && n_bkt) atomicAdd(&stats[STAT_BKT_CALCD], (unsigned long long)n_bkt);
@@ -571,28 +630,6 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 #endif
 template <typename P> __device__ __forceinline__ P pos_enc(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v + (uint64_t)BWB_TEST_POS_BIAS) : v; }
 template <typename P> __device__ __forceinline__ P pos_dec(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v - (uint64_t)BWB_TEST_POS_BIAS) : v; }
-
-/* Loads that are ISSUED AHEAD of the iteration's gather and land under the gather's wait, IN PLACE, for the lanes named by `mask`.  The
- * destination register holds live values in the other lanes, so the compiler will not let an ordinary load inside a divergent branch write
- * it: it loads into a scratch register and copies under the exec mask - and the copy waits for the load on the spot, which puts the memory
- * round trip back in front of the gather.  Here the load is one statement in uniform control flow whose asm narrows the exec mask itself: to
- * the compiler a plain read-modify-write of `dst`, which stays where it is.  THE RULE: the compiler does not know that the register is in
- * flight - nothing may read it until a vmcnt(0) wait has been executed (kl_search: the gather's own wait, or the explicit one after it when
- * no lane of the wave needed a rank).  tools/check_prefetch_regs.py verifies on the ISA of every build that no instruction touches these
- * registers in between. */
-__device__ __forceinline__ void prefetch128(u32x4 &dst, const void *p, unsigned long long mask) {
-	unsigned long long sv;
-	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx4 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
-}
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void prefetch64(u32x2 &dst, const void *p, unsigned long long mask) {
-	unsigned long long sv;
-	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dwordx2 %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
-}
-__device__ __forceinline__ void prefetch32(uint32_t &dst, const void *p, unsigned long long mask) {
-	unsigned long long sv;
-	asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tglobal_load_dword %[d], %[p], off\n\ts_mov_b64 exec, %[sv]" : [d] "+v"(dst), [sv] "=&s"(sv) : [p] "v"(p), [m] "s"(mask) : "memory", "scc");
-}
 
 /* heap entry.  NARROW (max_gapo <= 1): 16 bytes {L lo, U lo, i|mm|go|ge, state|alen<<2|run<<10|L hi<<26|U hi<<29};
  * WIDE: 32 bytes {L, U (64-bit each)} {i|mm|go|ge, state|alen<<8, runs lo, runs hi}.

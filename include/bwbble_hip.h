@@ -168,6 +168,9 @@ int bwb_hip_rank_bench_lane(bwb_hip_ctx *ctx, size_t n, int iters, uint64_t seed
  * (bwt.c:80) uploaded with bwb_hip_set_sa. Used by aln2sam (align.c:760-812). */
 int bwb_hip_set_sa(bwb_hip_ctx *ctx, const uint64_t *SA, uint64_t num_sa);
 int bwb_hip_locate(bwb_hip_ctx *ctx, const uint64_t *rows, size_t n, uint64_t *out_pos);
+/* the last bwb_hip_locate call on the context: rows looked up, invPsi steps taken (each one rank-block visit: a 128-byte bucket) and the
+ * kernel's HIP-event time - what `bwbble aln2sam` and bench.py report (any pointer may be NULL) */
+int bwb_hip_locate_stats(bwb_hip_ctx *ctx, uint64_t *rows, uint64_t *steps, double *kernel_ms);
 
 #ifdef __cplusplus
 }

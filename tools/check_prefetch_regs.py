@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool + CPU test helper: verifies on the ISA that the registers written by the in-place prefetches of kl_search
-(prefetch128 / prefetch32 in bwb_lane.h: global loads issued ahead of the gather by an asm that narrows the exec mask) are not touched
+"""Developer tool + CPU test helper: verifies on the ISA that the registers written by the in-place prefetches of kl_search and kl_calc_d
+(prefetch128 / 64 / 32 in bwb_lane.h: global loads issued ahead of the gather by an asm that narrows the exec mask) are not touched
 by any instruction until a vmcnt(0) wait has been executed.
 
 The compiler does not know that those registers are in flight: a copy, a spill or a use it placed between the load and the wait would
@@ -65,7 +65,7 @@ def check_asm(path, remarks=None, remarks_file=None):
         parse_remarks(open(remarks_file).read(), remarks)
     cur, kernels = None, {}
     for ln in open(path):
-        m = re.match(r"^(_Z\w*kl_search\w*):", ln)
+        m = re.match(r"^(_Z\w*(?:kl_search|kl_calc_d)\w*):", ln)
         if m:
             cur = m.group(1)
             kernels[cur] = []
