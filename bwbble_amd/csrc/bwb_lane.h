@@ -205,6 +205,9 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	/* (Tried, session 12: the loads as structured-buffer loads - record = slice, idle owners out of range, no exec mask, three instructions
 	 * a load instead of nine.  Correct on every test index and wrong at GRCh37 size: without swizzling the range check works on bytes,
 	 * 32 bits of them, and the table has 13.7 GB.) */
+#ifdef BWB_GATHER_PRIO
+	__builtin_amdgcn_s_setprio(0);
+#endif
 	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
 	                                       record, the heap entry a pop uncovered, the next list interval: all issued ahead of the gather) */
 	asm volatile("" ::: "memory");
@@ -1008,7 +1011,14 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #define mysave (R_sc(save) + (size_t)slotv * SAVE_U4)
 	auto xs = [&]() -> uint32_t * { return (uint32_t *)(mysave + 15); }; /* the tail and the length of the lane's excess chain (LHeap::alloc) */
 	const int lcap = (int)sc_lcap;
-	const int nb = kp.num_buckets;
+	/* The alignment parameters as OPAQUE scalars: seen through, the compiler drops them when it runs out of scalar registers and loads them
+	 * again from the kernarg segment inside the loop - 8.5 s_load + full lgkmcnt waits per wave iteration in the first round-5 builds
+	 * (tools/bbprof.py), each a round trip to the scalar cache in the path of a whole wave.  A value it cannot see through is kept, or parked
+	 * in a VGPR lane and fetched with one v_readlane. */
+	KParams kq = kp;
+	asm volatile("" : "+s"(kq.max_diff), "+s"(kq.max_gapo), "+s"(kq.max_gape), "+s"(kq.max_entries), "+s"(kq.mm_score), "+s"(kq.gapo_score), "+s"(kq.gape_score));
+	asm volatile("" : "+s"(kq.seed_length), "+s"(kq.max_diff_seed), "+s"(kq.max_best), "+s"(kq.no_indel_length), "+s"(kq.num_buckets), "+s"(kq.use_precalc));
+	const int nb = kq.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
 	const P last_row = (P)(ix.length - 1);
 
@@ -1018,8 +1028,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	h.pshared = ((gridDim.x + sc.n_regions - 1) / sc.n_regions) * LANE_BLOCK * sc.keep;
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow; h.nslots = sc.nslots;
 	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
-	h.pX = kp.mm_score; h.pGo = kp.gapo_score; h.pGe = kp.gape_score; h.nbk = nb;
-	h.far = WIDE && (kp.mm_score > 63 || kp.gapo_score > 63 || kp.gape_score > 63);
+	h.pX = kq.mm_score; h.pGo = kq.gapo_score; h.pGe = kq.gape_score; h.nbk = nb;
+	h.far = WIDE && (kq.mm_score > 63 || kq.gapo_score > 63 || kq.gape_score > 63);
 	h.fhead = NONE32;
 	h.reset();
 
@@ -1063,7 +1073,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	uint32_t n_bkt = 0, n_rec = 0; /* wave-uniform: buckets fetched, records loaded (heap entries stored / fetched: s_cnt) */
 	uint32_t acc_st = 0, acc_ld = 0; /* per lane, for the whole launch: heap entries stored / fetched (summed over the wave once, at the end) */
 	bool parked = false;
-	uint32_t age = 0; /* slices this lane's read has been parked at the end of (0: started in this launch) */
 #ifdef BWB_STAMPS
 	unsigned long long seg[16] = { 0 }, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -1089,7 +1098,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		nxi.L = p64(a5.x, a5.y); nxi.U = p64(a5.z, a5.w);
 		e.f = a6.x; e.sa = a6.y; e.runsLo = a6.z; e.runsHi = a6.w;
 		h.pused = a7.x; h.xhead = a7.y;
-		age = a7.z;
 		h.neW = ((uint64_t)a8.y << 32) | a8.x; h.cb = (int)a8.z; h.cst = a8.w;
 		h.side_load(); /* (the side buckets' states went to memory when the read was parked) */
 		h.num_entries = (int)a9.x; r_vis_s = a9.y; r_vis_a = a9.z; r_pop = a9.w;
@@ -1102,12 +1110,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	} else {
 		for (int k = 0; k < nb; k++) h.bstate[k] = NONE32;
 	}
-#ifdef BWB_AGE_PRIO
-	/* A wave that resumes a read which has already been through BWB_AGE_PRIO slices - the heavy tail: one read in a hundred takes 10-50 x the
-	 * median's iterations and decides when its slot can be used again and how long the stream's last launch lasts - issues ahead of its
-	 * SIMD's other waves for the rest of the launch: the same work, the long chains first. */
-	if (__any(active && age >= (uint32_t)BWB_AGE_PRIO)) __builtin_amdgcn_s_setprio(2);
-#endif
 
 	for (;;) {
 		STAMP(7);
@@ -1153,9 +1155,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				/* a read whose calculate_d overflowed its scratch class waits for the re-run of both kernels in a larger class */
 				const bool dfail = b.status[rid] == ST_D_OVF;
 				/* (an EMPTY read is searched like any other: its root entry is a hit with the whole index as its interval, :331-344) */
-				bool skip = cntN > kp.max_diff || unrep || dfail; /* inexact_match.c:260-266 */
+				bool skip = cntN > kq.max_diff || unrep || dfail; /* inexact_match.c:260-266 */
 				seeding = false;
-				if (kp.use_precalc && !skip) {
+				if (kq.use_precalc && !skip) {
 					/* -P.  A read with an N in the last 12 bases of rc (= the first 12 of seq) gets an empty record
 					 * (inexact_match.c:129-136).  Otherwise the heap starts from the precalculated list of that 12-mer
 					 * (:269-279); the list is exact_match() of the 12-mer (align.c:212-216), a pure function of it, so the
@@ -1174,8 +1176,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					if (!ovf0) { h.cst++; h.set_top((P)0, last_row, (uint32_t)rd_len, 0u, ~0u, ~0u); h.store_packed(h.cst, h.tw, h.tw1); h.cprev = NONE32; h.mark(0); h.num_entries = 1; }
 					r_push++;
 				}
-				SET_BEST_SCORE(kp.num_buckets); /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
-				SET_MAX_DIFF(kp.max_diff); num_best = 0;
+				SET_BEST_SCORE(kq.num_buckets); /* aln_score(max_diff+1,max_gapo+1,max_gape+1) :284 */
+				SET_MAX_DIFF(kq.max_diff); num_best = 0;
 				if (ovf0 || dfail) {
 					if (ovf0) b.status[rid] = ST_SCRATCH_OVF;
 					R_descs[R_wk(slot)].out.n[rid] = 0; (void)h.release_excess(xs); active = false;
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				mysave[14] = make_uint4(lo(nx.fL), hi(nx.fL), lo(nx.fU), hi(nx.fU));
 				mysave[5] = make_uint4(lo(nxi.L), hi(nxi.L), lo(nxi.U), hi(nxi.U));
 				mysave[6] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-				mysave[7] = make_uint4(h.pused, h.xhead, age + 1u, 0u);
+				mysave[7] = make_uint4(h.pused, h.xhead, 0u, 0u);
 				mysave[8] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), (uint32_t)h.cb, h.cst);
 				mysave[9] = make_uint4((uint32_t)h.num_entries, r_vis_s, r_vis_a, r_pop);
 				mysave[10] = make_uint4(r_push, 0u, 0u, 0u);
@@ -1249,13 +1251,16 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		};
 
 		STAMP(0);
+#if defined(BWB_GATHER_PRIO) && BWB_GATHER_PRIO == 2
+		__builtin_amdgcn_s_setprio(3);
+#endif
 		/* ---- A: pick the SA interval of this iteration ---- */
 		/* (Flat on purpose: with 64 reads per wave every path below is taken by some lane in nearly every iteration - tools/bbprof.py counts
 		 * 0.99 executions per wave iteration for all of them - so a nest of branches buys nothing and costs, per level, the scalar mask
 		 * bookkeeping and the copies of every value the branches merge: rounds 3-4 had four levels here.) */
 		const bool ex = active && exact_mode;      /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
 		const bool popping = active && !exact_mode;
-		const bool can_pop = popping && !(h.num_entries == 0 || h.num_entries > kp.max_entries); /* :293,299 */
+		const bool can_pop = popping && !(h.num_entries == 0 || h.num_entries > kq.max_entries); /* :293,299 */
 		if (can_pop) {
 			h.switch_cache(h.best(nb));
 #ifdef BWB_HIST
@@ -1269,7 +1274,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			const bool grp = can_pop && (e.sa & 3u) == (uint32_t)STATE_GROUP;
 			/* :309 (the reference pops that child, then stops).  aln_entry_t.score is an 8-bit field (align.h:104): what the reference compares is
 			 * the score modulo 256 - the same number unless the parameters allow scores above 255 */
-			const bool over = can_pop && (e_score & 255) > rd_best_score + kp.mm_score;
+			const bool over = can_pop && (e_score & 255) > rd_best_score + kq.mm_score;
 			finish = popping && (!can_pop || over);
 			r_pop += (can_pop && (!grp || over)) ? 1u : 0u;
 			from_pop = can_pop && !over;
@@ -1307,12 +1312,15 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		HISTW(H_WAVE_ALL_EXACT, __all(!active || exact_mode) ? 1 : 0);
 #endif
 		STAMP(1);
+#if defined(BWB_GATHER_PRIO) && BWB_GATHER_PRIO == 1
+		__builtin_amdgcn_s_setprio(3);
+#endif
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
 		uint32_t wd = 0, ws = 0, ne = 0;
 		int cr = 4, nvis = 0;
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
-		const bool want_rec = need_rank || (from_pop && rd_len < kp.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
+		const bool want_rec = need_rank || (from_pop && rd_len < kq.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
 		/* The record of the entry's position (D[i-1], D[i-2] | D_seed pair | seq[len - widx]: bwb_kernels.h) - the one in registers when its tag
 		 * matches, else one load.  It is only ISSUED here, in place (prefetch128), and unpacked after the rank: round 3 unpacked it on the spot
 		 * - a flat load, which the gather's wait for its exchange array waits for as well - so a wave sat out the record's round trip before
@@ -1352,8 +1360,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow;
 		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504); their states are in registers (LHeap) */
 		const int e_state = (int)(e.sa & 3u);
-		const int scX = e_score + kp.mm_score, scG = e_score + (e_state == STATE_M ? kp.gapo_score : kp.gape_score);
-		const int wG = e_state == STATE_M ? h.side_of(kp.gapo_score) : h.side_of(kp.gape_score); /* which register is the gap bucket's (0: the cached bucket itself) */
+		const int scX = e_score + kq.mm_score, scG = e_score + (e_state == STATE_M ? kq.gapo_score : kq.gape_score);
+		const int wG = e_state == STATE_M ? h.side_of(kq.gapo_score) : h.side_of(kq.gape_score); /* which register is the gap bucket's (0: the cached bucket itself) */
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
 		if (!MULTI) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
@@ -1390,8 +1398,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const int e_i = e.f & 255, e_mm = (e.f >> 8) & 255, e_go = (e.f >> 16) & 255, e_ge = (e.f >> 24) & 255;
 		const int e_alen = (int)((e.sa >> 2) & 255u);
 		const int diff_left = rd_max_diff - e_mm - e_go - e_ge;
-		const int diff_left_seed = kp.max_diff_seed - e_mm - e_go - e_ge;
-		const int seed_index = e_i - (rd_len - kp.seed_length);
+		const int diff_left_seed = kq.max_diff_seed - e_mm - e_go - e_ge;
+		const int seed_index = e_i - (rd_len - kq.seed_length);
 		const bool pruned = diff_left < 0                                                          /* :313 */
 		                    || (e_i > 0 && diff_left < (int)(wd & 127u))                            /* :317 */
 		                    || (seed_index > 0 && diff_left_seed < (int)(ws & 127u));               /* :326 */
@@ -1406,10 +1414,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			if (n_alns == 0) {
 				SET_BEST_SCORE(e_score);
 				const int bd = e_mm + e_go + e_ge;
-				SET_MAX_DIFF((bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1);
+				SET_MAX_DIFF((bd + 1 > kq.max_diff) ? kq.max_diff : bd + 1);
 			}
 			if (e_score == rd_best_score) { num_best += (int)(uint32_t)(e.U - e.L + 1); add_aln(e.L, e.U, e_score, e_alen); }
-			else if (num_best > kp.max_best) finish = true;
+			else if (num_best > kq.max_best) finish = true;
 			else add_aln(e.L, e.U, e_score, e_alen);
 		}
 		{ /* exact tail :345-375: its first step uses the children just computed (cL / cU are e.L / e.U already) */
@@ -1434,10 +1442,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
 			}
 			const int tmp = e_go + e_ge;
-			if ((e_i - 1 < kp.no_indel_length + tmp) || ((rd_len - (e_i - 1)) < kp.no_indel_length + tmp)) allow_indels = false;
-			if (e_go >= kp.max_gapo && e_ge >= kp.max_gape) allow_indels = false;
-			if (e_go >= kp.max_gapo) allow_open = false;
-			if (e_ge >= kp.max_gape) allow_extend = false;
+			if ((e_i - 1 < kq.no_indel_length + tmp) || ((rd_len - (e_i - 1)) < kq.no_indel_length + tmp)) allow_indels = false;
+			if (e_go >= kq.max_gapo && e_ge >= kq.max_gape) allow_indels = false;
+			if (e_go >= kq.max_gapo) allow_open = false;
+			if (e_ge >= kq.max_gape) allow_extend = false;
 			const bool gap_open = e_state == STATE_M;
 			const int sc0 = e_score;
 			const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
@@ -1459,7 +1467,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nGc; hl_mis += nX; hl_match += n0; }
 #endif
 			/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
-			const int tX = kp.mm_score == 0 ? 0 : 1, tG = wG == 0 ? 0 : (wG == 1 ? 1 : 2);
+			const int tX = kq.mm_score == 0 ? 0 : 1, tG = wG == 0 ? 0 : (wG == 1 ? 1 : 2);
 			const int k0 = n0 + (tX == 0 ? nX : 0) + (tG == 0 ? nG : 0);
 			const int k1 = (tX == 1 ? nX : 0) + (tG == 1 ? nG : 0);
 			const int k2 = tG == 2 ? nG : 0;
@@ -1506,7 +1514,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				}
 				STAMP(12);
 				const uint32_t sm = (uint32_t)STATE_M | (alen1 << 2);
-				if (kp.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
+				if (kq.mm_score != 0) { /* mismatches and matches land on different buckets: two independent sequences */
 					uint32_t sxm = tX == 1 ? s1 : s0;
 					uint32_t xm = mism;
 					while (xm) {
@@ -1634,13 +1642,13 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					if (n_alns == 0) {
 						SET_BEST_SCORE(e_score);
 						const int bd = e_mm + e_go + e_ge;
-						SET_MAX_DIFF((bd + 1 > kp.max_diff) ? kp.max_diff : bd + 1);
+						SET_MAX_DIFF((bd + 1 > kq.max_diff) ? kq.max_diff : bd + 1);
 					}
 					bool brk = false;
 					/* num_best += the width of every interval of the list (:350-352): adjacent intervals merge without changing the
 					 * sum, so it is the running sum of what the last step added - no pass over the list in memory */
 					if (e_score == rd_best_score) num_best += (int)lastW;
-					else if (num_best > kp.max_best) brk = true;
+					else if (num_best > kq.max_best) brk = true;
 					if (brk) finish = true;
 					else {
 						const int alen2 = ((int)((e.sa >> 2) & 255u) + e_i) & 255; /* :365 */
