@@ -22,7 +22,7 @@ EXPORTS = [
     "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate", "bwb_hip_locate_stats",
     "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush", "bwb_hip_abi_version", "bwb_hip_ctx_create_streamed", "bwb_hip_device_numa_node",
 ]
-ABI_VERSION = 2  # BWB_HIP_ABI_VERSION (include/bwbble_hip.h)
+ABI_VERSION = 3  # BWB_HIP_ABI_VERSION (include/bwbble_hip.h)
 MAX_SLOTS = 8  # BWB_MAX_SLOTS
 
 
@@ -48,8 +48,8 @@ class Stats(C.Structure):
 
 
 ALN_DTYPE = np.dtype([("L", "<u8"), ("U", "<u8"), ("score", "<u2"), ("num_mm", "u1"), ("num_gapo", "u1"),
-                      ("num_gape", "u1"), ("reserved", "u1"), ("aln_length", "<u2"), ("gap_run", "<u2", (4,))])
-assert ALN_DTYPE.itemsize == 32
+                      ("num_gape", "u1"), ("reserved", "u1"), ("aln_length", "<u2"), ("gap_run", "<u2", (8,)), ("reserved2", "<u8")])
+assert ALN_DTYPE.itemsize == 48
 
 _FLAG = {"-M": "mm_score", "-O": "gapo_score", "-E": "gape_score", "-n": "max_diff", "-k": "max_diff_seed",
          "-o": "max_gapo", "-e": "max_gape", "-l": "seed_length", "-m": "max_entries", "-t": "n_threads"}

@@ -157,6 +157,7 @@ struct bwb_hip_ctx {
 };
 
 extern "C" const char *bwb_hip_last_error(void) { return g_err.c_str(); }
+static_assert(sizeof(bwb_aln) == 16 * ALN_U4, "bwb_aln is ALN_U4 16-byte words (bwb_lane.h)");
 extern "C" int bwb_hip_abi_version(void) { return BWB_HIP_ABI_VERSION; }
 
 /* NUMA node of the device's PCIe root (sysfs), -1 when the machine has one node or it cannot be told: `bwbble align` pins the host
@@ -319,9 +320,9 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	 * come - the scratch of the re-run classes and their pool, three more slots like the largest so far, some slack - and what
 	 * the regions can name: a state word holds a 26-bit chunk index relative to the block's region. */
 	const size_t isz = c->pos32 ? 8 : 16;
-	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * 32), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * 32);
+	const size_t cls1 = (size_t)std::max(1, c->num_cu / 2) * LANE_BLOCK * (2 * 8192 * isz + 1024 * sizeof(bwb_aln)), cls2 = (size_t)LANE_BLOCK * (2 * ((size_t)1 << 20) * isz + 65536 * sizeof(bwb_aln));
 	size_t slot_bytes = 0;
-	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * 32);
+	for (const Slot &s : c->slots) slot_bytes = std::max(slot_bytes, s.d_reads.bytes + s.d_dbuf.bytes + s.d_log.bytes + (size_t)s.n_reads * sizeof(bwb_aln));
 	/* (every slot still to come like the largest so far: a stream needs them all - the heaviest reads of a batch take several slices'
 	 * time, DESIGN.md section 2.3 - and 8 x 3 GB is little next to the pool) */
 	size_t more_slots = 0; /* slots that have no buffers yet (a caller that uploads every slot before the first submit - bench.py - has none left) */
@@ -397,7 +398,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	const size_t isz = c->pos32 ? 8 : 16;
 	auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
 	const uint32_t brow = std::max<uint32_t>(BSTATE_ROW_MIN, ((uint32_t)c->kp.num_buckets + 63u) & ~63u);
-	const size_t b_bstate = al((size_t)brow * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * 32),
+	const size_t b_bstate = al((size_t)brow * nslots * 4), b_lists = al((size_t)nslots * 2 * lcap * isz), b_alns = al((size_t)nslots * acap * sizeof(bwb_aln)),
 	             b_save = al((size_t)nslots * SAVE_U4 * 16), b_bsave = al((size_t)blocks * 16);
 	/* class 0 runs kl_calc_d of the next batch while parked reads keep their lists: it gets a second set; the re-run classes
 	 * are drained before anything else uses them */
@@ -452,7 +453,7 @@ static int resolve_times(bwb_hip_ctx *c, bool all) {
 }
 
 static int check_params(const bwb_params *p, int *nb_out) {
-	if (p->max_gapo < 0 || p->max_gapo > 4) return fail(BWB_E_ARG, "max_gapo (-o) must be in [0,4] on the GPU path");
+	if (p->max_gapo < 0 || p->max_gapo > BWB_MAX_GAP_RUNS) return fail(BWB_E_ARG, "max_gapo (-o) must be in [0,8] on the GPU path (a heap entry and a hit record hold eight gap runs)");
 	if (p->max_gape < 0 || p->max_gape > 100 || p->max_diff < 0 || p->max_diff > 100) return fail(BWB_E_ARG, "max_gape/max_diff out of the supported range [0,100]");
 	if (p->seed_length < 0 || p->seed_length > 255) return fail(BWB_E_ARG, "seed_length must be in [0,255]");
 	if (p->mm_score < 0 || p->gapo_score < 0 || p->gape_score < 0) return fail(BWB_E_ARG, "negative penalties are not supported");
@@ -546,7 +547,7 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	HIPCHK(s.h_ctl.reserve(256));
 	HIPCHK(s.ev_up.create());
 	const uint64_t want = std::max<uint64_t>((uint64_t)nr * 8, 1u << 16); /* hit log: 8 records per read, grown on demand */
-	if (s.log_cap < want) { HIPCHK(s.d_log.alloc(want * 32)); s.log_cap = want; }
+	if (s.log_cap < want) { HIPCHK(s.d_log.alloc(want * sizeof(bwb_aln))); s.log_cap = want; }
 	if (c->dbg_iters) { HIPCHK(s.d_dbg_iters.reserve(nr * 4)); HIPCHK(hipMemsetAsync(s.d_dbg_iters.p, 0, nr * 4, c->cstream)); }
 	/* staging: the caller's buffers are free again when this returns; the copy to HBM proceeds on the copy stream */
 	HIPCHK(s.h_reads.reserve(nr * s.stride));
@@ -743,8 +744,8 @@ static int grow_log(bwb_hip_ctx *c, int si) {
 	const uint64_t valid = std::min<uint64_t>(cnt, s.log_cap);
 	const uint64_t ncap = s.log_cap * 4;
 	DevMem nl;
-	HIPCHK(nl.alloc(ncap * 32));
-	HIPCHK(hipMemcpyAsync(nl.p, s.d_log.p, valid * 32, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(nl.alloc(ncap * sizeof(bwb_aln)));
+	HIPCHK(hipMemcpyAsync(nl.p, s.d_log.p, valid * sizeof(bwb_aln), hipMemcpyDeviceToDevice, c->stream));
 	cnt = valid;
 	HIPCHK(hipMemcpyAsync(s.ctl_count(), &cnt, 8, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -887,8 +888,8 @@ extern "C" int bwb_hip_slot_result(bwb_hip_ctx *c, int si, bwb_result *out) {
 			HIPCHK(hipStreamSynchronize(c->rstream));
 			cnt = std::min<unsigned long long>(*s.h_ctl.as<unsigned long long>(), s.log_cap);
 			if (cnt) {
-				HIPCHK(s.h_log.reserve((size_t)cnt * 32));
-				HIPCHK(hipMemcpyAsync(s.h_log.p, s.d_log.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->rstream));
+				HIPCHK(s.h_log.reserve((size_t)cnt * sizeof(bwb_aln)));
+				HIPCHK(hipMemcpyAsync(s.h_log.p, s.d_log.p, (size_t)cnt * sizeof(bwb_aln), hipMemcpyDeviceToHost, c->rstream));
 				HIPCHK(hipStreamSynchronize(c->rstream));
 			}
 		}
@@ -903,7 +904,7 @@ extern "C" int bwb_hip_slot_result(bwb_hip_ctx *c, int si, bwb_result *out) {
 		for (uint32_t i = 0; i < n; i++) {
 			if (!hc[i]) continue;
 			if (ho[i] + hc[i] > cnt) return fail(BWB_E_STATE, "slot_result: a read's hits lie outside the hit log");
-			memcpy(&s.h_alns[s.h_aln_off[i]], hl + ho[i], (size_t)hc[i] * 32);
+			memcpy(&s.h_alns[s.h_aln_off[i]], hl + ho[i], (size_t)hc[i] * sizeof(bwb_aln));
 		}
 		s.fetched = true;
 	}

@@ -42,7 +42,7 @@ struct Batch {
 };
 
 struct OutBuf {
-	uint4 *alns;              /* the slot's hit log, 32 B records */
+	uint4 *alns;              /* the slot's hit log, 48-byte records (bwb_aln: three uint4) */
 	unsigned long long *count;
 	uint64_t cap;
 	uint64_t *off;            /* per read: first record */

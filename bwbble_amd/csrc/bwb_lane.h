@@ -47,6 +47,7 @@ template <typename P> using Lds = __attribute__((address_space(3))) P *;
 #define PRECALC_LEN 12            /* PRECALC_INTERVAL_LENGTH align.h:31 */
 #define ADMIT_CHUNKS 1024        /* free chunks a block wants to see per read it starts once the pool runs low */
 #define SAVE_U4 16               /* uint4 per lane in the save area */
+#define ALN_U4 3                 /* uint4 per hit record: bwb_aln is 48 bytes (include/bwbble_hip.h) */
 
 struct LaneScratch {
 	uint4 *pool;                /* chunk pool in POOL_REGIONS regions (block b uses region b % n_regions: its XCD's when all 8 are in use):
@@ -635,13 +636,15 @@ template <typename P> __device__ __forceinline__ P pos_enc(P v) { return sizeof(
 template <typename P> __device__ __forceinline__ P pos_dec(P v) { return sizeof(P) == 8 ? (P)((uint64_t)v - (uint64_t)BWB_TEST_POS_BIAS) : v; }
 
 /* heap entry.  NARROW (max_gapo <= 1): 16 bytes {L lo, U lo, i|mm|go|ge, state|alen<<2|run<<10|L hi<<26|U hi<<29};
- * WIDE: 32 bytes {L, U (64-bit each)} {i|mm|go|ge, state|alen<<8, runs lo, runs hi}.
+ * WIDE: 32 bytes {L lo, U lo, i|mm|go|ge, state|alen<<2|L hi<<26|U hi<<29} {eight gap runs} (round 5: -o up to 8; rounds 3-4 kept the
+ * positions as two 64-bit words and had room for four runs).
  * runs: one 16-bit word per gap open: start | len<<8 | isD<<15, 0xFFFF = unused. */
 template <typename P> struct LEntry {
 	P L, U;
 	uint32_t f;        /* i | mm<<8 | go<<16 | ge<<24 */
 	uint32_t sa;       /* state | alen<<2 */
-	uint32_t runsLo, runsHi;
+	uint32_t runsLo, runsHi;   /* gap runs 0..3 */
+	uint32_t runs2Lo, runs2Hi; /* gap runs 4..7 (32-byte entries only) */
 };
 
 /* Score-bucketed LIFO heap (inexact_match.h:17-34, inexact_match.c:510-610): every bucket is a chain of 64-slot
@@ -817,21 +820,22 @@ template <typename P, bool WIDE> struct LHeap {
 		return st;
 	}
 	/* an entry in the form it has in memory: w0 (and w1 when WIDE) */
-	static __device__ __forceinline__ void pack(P L, P U, uint32_t f, uint32_t sa, uint32_t runsLo, uint32_t runsHi, u32x4 &w0, u32x4 &w1) {
+	static __device__ __forceinline__ void pack(P L, P U, uint32_t f, uint32_t sa, uint32_t runsLo, uint32_t runsHi, u32x4 &w0, u32x4 &w1, uint32_t runs2Lo = ~0u, uint32_t runs2Hi = ~0u) {
 		L = pos_enc<P>(L); U = pos_enc<P>(U);
 		if (WIDE) {
-			w0 = u32x4{ (uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32) };
-			w1 = u32x4{ f, sa, runsLo, runsHi };
+			w0 = u32x4{ (uint32_t)L, (uint32_t)U, f, pack_w(L, U, sa & 0x3FFu, 0u) };
+			w1 = u32x4{ runsLo, runsHi, runs2Lo, runs2Hi };
 		} else w0 = u32x4{ (uint32_t)L, (uint32_t)U, f, pack_w(L, U, sa, runsLo) };
 	}
 	static __device__ __forceinline__ void unpack(const u32x4 w0, const u32x4 w1, LEntry<P> &e) {
+		e.L = (P)w0.x; e.U = (P)w0.y; e.f = w0.z;
+		if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w0.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w0.w >> 29) << 32); }
 		if (WIDE) {
-			e.L = (P)(((uint64_t)w0.y << 32) | w0.x); e.U = (P)(((uint64_t)w0.w << 32) | w0.z);
-			e.f = w1.x; e.sa = w1.y; e.runsLo = w1.z; e.runsHi = w1.w;
+			e.sa = w0.w & 0x3FFu;
+			e.runsLo = w1.x; e.runsHi = w1.y; e.runs2Lo = w1.z; e.runs2Hi = w1.w;
 		} else {
-			e.L = (P)w0.x; e.U = (P)w0.y; e.f = w0.z; e.sa = w0.w & 0x3FFFFFFu; /* (state | aln_length << 2 | the one gap run << 10: ERUNS_LO; one register, not two) */
-			if (sizeof(P) == 8) { e.L |= (P)((uint64_t)((w0.w >> 26) & 7u) << 32); e.U |= (P)((uint64_t)(w0.w >> 29) << 32); }
-			e.runsLo = 0xFFFFFFFFu; e.runsHi = 0xFFFFFFFFu; /* (not used with 16-byte entries: the run is in e.sa) */
+			e.sa = w0.w & 0x3FFFFFFu; /* (state | aln_length << 2 | the one gap run << 10: ERUNS_LO; one register, not two) */
+			e.runsLo = 0xFFFFFFFFu; e.runsHi = 0xFFFFFFFFu; e.runs2Lo = 0xFFFFFFFFu; e.runs2Hi = 0xFFFFFFFFu; /* (not used with 16-byte entries: the run is in e.sa) */
 		}
 		e.L = pos_dec<P>(e.L); e.U = pos_dec<P>(e.U);
 	}
@@ -850,7 +854,7 @@ template <typename P, bool WIDE> struct LHeap {
 		top_valid = true;
 	}
 	/* the entry (L, U, f, sa, runs) becomes the top of the cached bucket, in registers only (the caller has reserved its slot and counted it) */
-	__device__ __forceinline__ void set_top(P L, P U, uint32_t f, uint32_t sa, uint32_t runsLo, uint32_t runsHi) { pack(L, U, f, sa, runsLo, runsHi, tw, tw1); top_valid = true; }
+	__device__ __forceinline__ void set_top(P L, P U, uint32_t f, uint32_t sa, uint32_t runsLo, uint32_t runsHi) { pack(L, U, f, sa, runsLo, runsHi, tw, tw1); top_valid = true; } /* (entries without a gap: runs 4..7 unused) */
 	/* Pops the top entry of the cached bucket cb (the best non-empty one).  n_ld += 1 when an entry is fetched from memory.  What the pop
 	 * uncovers comes from the second mirror register, else from memory: pf_top = its state word, pf_hdr = the chunk whose header word is
 	 * wanted for cprev (NONE32: nothing to fetch) - the caller issues both with prefetch() where the lanes of the wave have met again. */
@@ -1007,7 +1011,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	uint32_t sc_lcap = sc.lcap, sc_acap = sc.acap, sc_brow = sc.brow;
 	asm volatile("" : "+s"(sc_lists), "+s"(sc_alns), "+s"(sc_bstate), "+s"(sc_lcap), "+s"(sc_acap), "+s"(sc_brow));
 #define lbase ((Intv<P> *)(unsigned char *)sc_lists + (size_t)slotv * 2 * sc_lcap)
-#define myalns ((uint4 *)(unsigned char *)sc_alns + (size_t)slotv * sc_acap * 2)
+#define myalns ((uint4 *)(unsigned char *)sc_alns + (size_t)slotv * sc_acap * ALN_U4)
 #define mysave (R_sc(save) + (size_t)slotv * SAVE_U4)
 	auto xs = [&]() -> uint32_t * { return (uint32_t *)(mysave + 15); }; /* the tail and the length of the lane's excess chain (LHeap::alloc) */
 	const int lcap = (int)sc_lcap;
@@ -1055,10 +1059,12 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	uint32_t nxw = 0;                                       /* exact tail: summed width of the intervals added to the next list so far (wrapping, like the
 	                                                           reference's int num_best sum :350-352) */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
-	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = ~0u;
+	LEntry<P> e; e.L = e.U = 0; e.f = 0; e.sa = 0; e.runsLo = e.runsHi = e.runs2Lo = e.runs2Hi = ~0u;
 	/* the popped entry's gap runs: four 16-bit words with 32-byte entries; with 16-byte entries the single run travels in bits 10..25 of e.sa */
 #define ERUNS_LO (WIDE ? e.runsLo : (0xFFFF0000u | ((e.sa >> 10) & 0xFFFFu)))
 #define ERUNS_HI (WIDE ? e.runsHi : 0xFFFFFFFFu)
+#define ERUNS2_LO (WIDE ? e.runs2Lo : 0xFFFFFFFFu)
+#define ERUNS2_HI (WIDE ? e.runs2Hi : 0xFFFFFFFFu)
 	/* the tail (last interval) of the current list of an exact tail lives in the registers of the popped entry's interval: the tail starts as
 	 * that interval (:345-347), and the entry's interval is not looked at again once its exact tail has begun (registers decide whether three
 	 * waves fit a SIMD) */
@@ -1097,13 +1103,13 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		{ const uint4 a14 = mysave[14]; nx.fL = p64(a14.x, a14.y); nx.fU = p64(a14.z, a14.w); }
 		nxi.L = p64(a5.x, a5.y); nxi.U = p64(a5.z, a5.w);
 		e.f = a6.x; e.sa = a6.y; e.runsLo = a6.z; e.runsHi = a6.w;
-		h.pused = a7.x; h.xhead = a7.y;
+		h.pused = a7.x; h.xhead = a7.y; e.runs2Lo = a7.z; e.runs2Hi = a7.w;
 		h.neW = ((uint64_t)a8.y << 32) | a8.x; h.cb = (int)a8.z; h.cst = a8.w;
 		h.side_load(); /* (the side buckets' states went to memory when the read was parked) */
 		h.num_entries = (int)a9.x; r_vis_s = a9.y; r_vis_a = a9.z; r_pop = a9.w;
 		r_push = a10.x;
 		h.tw = v4(a11); h.tw1 = v4(a12); h.sw = v4(a13);
-		if (!WIDE) e.runsLo = e.runsHi = ~0u; /* (16-byte entries: the one gap run is part of e.sa, LHeap::unpack) */
+		if (!WIDE) e.runsLo = e.runsHi = e.runs2Lo = e.runs2Hi = ~0u; /* (16-byte entries: the one gap run is part of e.sa, LHeap::unpack) */
 		rec.w = 0xFFFF0000u;
 		active = true;
 		__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1204,7 +1210,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				mysave[14] = make_uint4(lo(nx.fL), hi(nx.fL), lo(nx.fU), hi(nx.fU));
 				mysave[5] = make_uint4(lo(nxi.L), hi(nxi.L), lo(nxi.U), hi(nxi.U));
 				mysave[6] = make_uint4(e.f, e.sa, e.runsLo, e.runsHi);
-				mysave[7] = make_uint4(h.pused, h.xhead, 0u, 0u);
+				mysave[7] = make_uint4(h.pused, h.xhead, e.runs2Lo, e.runs2Hi);
 				mysave[8] = make_uint4((uint32_t)h.neW, (uint32_t)(h.neW >> 32), (uint32_t)h.cb, h.cst);
 				mysave[9] = make_uint4((uint32_t)h.num_entries, r_vis_s, r_vis_a, r_pop);
 				mysave[10] = make_uint4(r_push, 0u, 0u, 0u);
@@ -1240,13 +1246,14 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			const int e_go = (e.f >> 16) & 255;
 			if (e_go) {
 				for (int j = 0; j < n_alns; j++) {
-					const uint4 a = myalns[j * 2];
+					const uint4 a = myalns[j * ALN_U4];
 					if (a.x == (uint32_t)L && a.y == (uint32_t)((uint64_t)L >> 32) && a.z == (uint32_t)U && a.w == (uint32_t)((uint64_t)U >> 32)) return;
 				}
 			}
 			if (n_alns >= (int)sc_acap) { ovf = true; return; }
-			myalns[n_alns * 2] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
-			myalns[n_alns * 2 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), ERUNS_LO, ERUNS_HI); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
+			myalns[n_alns * ALN_U4] = make_uint4((uint32_t)L, (uint32_t)((uint64_t)L >> 32), (uint32_t)U, (uint32_t)((uint64_t)U >> 32));
+			myalns[n_alns * ALN_U4 + 1] = make_uint4((uint32_t)(score & 0xFFFF) | ((e.f << 8) & 0xFFFF0000u), (e.f >> 24) | ((uint32_t)(alen & 255) << 16), ERUNS_LO, ERUNS_HI); /* bwb_aln: score16 | mm | go, ge | - | alen16 */
+			myalns[n_alns * ALN_U4 + 2] = make_uint4(ERUNS2_LO, ERUNS2_HI, 0u, 0u); /* gap runs 4..7 */
 			n_alns++;
 		};
 
@@ -1386,7 +1393,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					P cl, cu;
 					kid(j, cl, cu);
 					u32x4 w0, w1;
-					h.pack(cl, cu, e.f, sd & 0x3FFu, ERUNS_LO, ERUNS_HI, w0, w1);
+					h.pack(cl, cu, e.f, sd & 0x3FFu, ERUNS_LO, ERUNS_HI, w0, w1, ERUNS2_LO, ERUNS2_HI);
 					if (gm) { h.store_packed(++sx, w0, w1); st_cnt++; if (!WIDE) h.sw = w0; }
 					else { h.tw = w0; h.tw1 = w1; } /* (the last child is popped next: the register mirror is its only copy) */
 				}
@@ -1485,31 +1492,41 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const uint32_t f_match = (uint32_t)((e_i - 1) & 255) | ((uint32_t)e_mm << 8) | f_base;
 				const uint32_t f_mis = (uint32_t)((e_i - 1) & 255) | ((uint32_t)((e_mm + 1) & 255) << 8) | f_base;
 				const uint32_t f_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
-				const uint64_t eruns = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO;
-				uint64_t gruns_i, gruns_d; /* new run on open (start = aln_length, len 1); len+1 on extend */
+				const uint64_t eruns = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO, eruns2 = ((uint64_t)ERUNS2_HI << 32) | ERUNS2_LO;
+				uint64_t gruns_i, gruns_d, gruns2 = eruns2; /* new run on open (start = aln_length, len 1); len+1 on extend; runs 4..7 (32-byte entries) in gruns2 */
 				if (gap_open) {
 					const int sh = 16 * (e_go & 3);
-					const uint64_t cleared = eruns & ~(0xFFFFull << sh);
-					gruns_i = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh);
-					gruns_d = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
-				} else gruns_i = gruns_d = eruns + (0x100ull << (16 * ((e_go - 1) & 3)));
+					const bool hi4 = WIDE && e_go >= 4; /* (a fifth to eighth gap open: the run goes into the second word pair, an insertion and a deletion alike but for bit 15) */
+					const uint64_t src = hi4 ? eruns2 : eruns;
+					const uint64_t cleared = src & ~(0xFFFFull << sh);
+					const uint64_t vi = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh), vd = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
+					gruns_i = hi4 ? eruns : vi; gruns_d = hi4 ? eruns : vd;
+					if (hi4) gruns2 = vi; /* (deletion: bit 15 of the new run, set where it is emitted: G2D) */
+				} else {
+					const bool hi4 = WIDE && e_go - 1 >= 4;
+					const uint64_t inc = 0x100ull << (16 * ((e_go - 1) & 3));
+					gruns_i = gruns_d = hi4 ? eruns : eruns + inc;
+					if (hi4) gruns2 = eruns2 + inc;
+				}
+				/* the deletion's version of the second word pair: the run just opened there carries bit 15 */
+				const uint64_t gruns2_d = (WIDE && gap_open && e_go >= 4) ? (gruns2 | (0x8000ull << (16 * (e_go & 3)))) : gruns2;
 				/* the slot last used on every target bucket (a state word is also the slot's index in the pool: chunk << 6 | fill) */
 				uint32_t s0 = st0, s1 = st1, s2 = st2;
-				auto emit = [&](uint32_t &sx, P L, P U, uint32_t f, uint32_t sa, uint64_t runs) {
+				auto emit = [&](uint32_t &sx, P L, P U, uint32_t f, uint32_t sa, uint64_t runs, uint64_t runs2) {
 					u32x4 w0, w1;
-					h.pack(L, U, f, sa, (uint32_t)runs, (uint32_t)(runs >> 32), w0, w1);
+					h.pack(L, U, f, sa, (uint32_t)runs, (uint32_t)(runs >> 32), w0, w1, (uint32_t)runs2, (uint32_t)(runs2 >> 32));
 					h.store_packed(++sx, w0, w1);
-					st_cnt++; /* (per lane and iteration; summed over the wave where the lanes meet again: wave_sum5) */
+					st_cnt++; /* (per lane and iteration; summed over the wave once per launch) */
 				};
 				bool top_ok = false; /* does the register mirror hold the last entry pushed on bucket sc0? */
 				STAMP(11);
 				{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
 				   * holds the parent's interval (a single deletion child is stored as itself) */
 					uint32_t sg = tG == 0 ? s0 : (tG == 1 ? s1 : s2);
-					if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i);
+					if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, gruns2);
 					const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
-					if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d); }
-					else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d);
+					if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, gruns2_d); }
+					else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, gruns2_d);
 					if (tG == 0) s0 = sg; else if (tG == 1) s1 = sg; else s2 = sg;
 				}
 				STAMP(12);
@@ -1522,7 +1539,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						xm &= xm - 1;
 						P cl, cu;
 						kid(j, cl, cu);
-						emit(sxm, cl, cu, f_mis, sm, eruns);
+						emit(sxm, cl, cu, f_mis, sm, eruns, eruns2);
 					}
 					if (tX == 1) s1 = sxm; else s0 = sxm;
 					/* The last match child is the next entry popped (same score, LIFO, and nothing is ever pushed below the bucket being
@@ -1543,19 +1560,19 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 								P cl, cu;
 								kid(j, cl, cu);
 								u32x4 w0, w1;
-								h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1);
+								h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1, ERUNS2_LO, ERUNS2_HI);
 								h.store_packed(++s0, w0, w1); st_cnt++;
 							}
 							P cl, cu;
 							kid(j2, cl, cu);
 							u32x4 w0, w1;
-							h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1);
+							h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, w0, w1, ERUNS2_LO, ERUNS2_HI);
 							h.store_packed(++s0, w0, w1); st_cnt++;
 							if (!WIDE) { h.sw = w0; h.sec_valid = true; }
 						} else if (!WIDE) { h.sw = h.tw; h.sec_valid = h.top_valid && k0 == 1; } /* (what the pop uncovered: from the second mirror register, or on its way from memory) */
 						P cl, cu;
 						kid(jt, cl, cu);
-						h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, h.tw, h.tw1);
+						h.pack(cl, cu, f_match, sm, ERUNS_LO, ERUNS_HI, h.tw, h.tw1, ERUNS2_LO, ERUNS2_HI);
 						top_ok = true;
 					}
 				} else { /* mm_score == 0: one bucket, interleaved in code order */
@@ -1565,7 +1582,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						am &= am - 1;
 						P cl, cu;
 						kid(j, cl, cu);
-						emit(s0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns);
+						emit(s0, cl, cu, ((mem >> j) & 1u) ? f_match : f_mis, sm, eruns, eruns2);
 					}
 				}
 				STAMP(13);
@@ -1708,7 +1725,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			if (!ovf && n_alns > 0) {
 				off = atomicAdd(out.count, (unsigned long long)n_alns);
 				if (off + (unsigned long long)n_alns > out.cap) outovf = true;
-				else for (int t = 0; t < n_alns * 2; t++) out.alns[off * 2 + t] = myalns[t];
+				else for (int t = 0; t < n_alns * ALN_U4; t++) out.alns[off * ALN_U4 + t] = myalns[t];
 			}
 			out.off[rid] = off;
 			out.n[rid] = (ovf || outovf) ? 0u : (uint32_t)n_alns;
@@ -1766,6 +1783,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #undef lbase
 #undef ERUNS_LO
 #undef ERUNS_HI
+#undef ERUNS2_LO
+#undef ERUNS2_HI
 #undef KARGS
 #undef R_descs
 #undef R_wk

@@ -9,7 +9,7 @@
 /* the edit path is all STATE_M(0) except for the gap runs recorded by the kernel */
 int aln_path_bytes(const bwb_aln *a, unsigned char *path) {
 	memset(path, 0, 272);
-	for (int k = 0; k < 4; k++) {
+	for (int k = 0; k < BWB_MAX_GAP_RUNS; k++) {
 		const unsigned run = a->gap_run[k];
 		if (run == 0xFFFFu) continue;
 		const unsigned start = run & 0xFF, len = (run >> 8) & 0x7F, st = (run >> 15) ? 2 : 1; /* STATE_D : STATE_I */
@@ -50,6 +50,7 @@ void alns2alnf_bin(const bwb_aln *alns, uint64_t n, FILE *f) {
 /* The records of a whole chunk of reads as ONE byte buffer (round 5: built by the GPU worker that received the chunk's hits, with all
  * cores, so that the ordered writer only write()s; per-read fwrites in the writer thread were what a stream of several GPUs queued
  * behind).  Same bytes as alns2alnf_bin read by read.  Returns the malloc'ed buffer, *len = its length. */
+static inline int aln_nogap(const bwb_aln *a) { uint64_t r[2]; memcpy(r, a->gap_run, 16); return (r[0] & r[1]) == ~0ull; }
 static inline size_t aln_rec_bytes(const bwb_aln *a) {
 	/* 36 bytes of fixed fields + the pair count + one pair per run of equal states in the path */
 	if (a->aln_length == 0) return 40;
@@ -62,7 +63,7 @@ static inline size_t aln_rec_bytes(const bwb_aln *a) {
 static inline unsigned char *aln_rec_put(const bwb_aln *a, unsigned char *o) {
 	int32_t hdr[9];
 	unsigned char path[272];
-	const int nogap = a->gap_run[0] == 0xFFFFu && a->gap_run[1] == 0xFFFFu && a->gap_run[2] == 0xFFFFu && a->gap_run[3] == 0xFFFFu;
+	const int nogap = aln_nogap(a);
 	const int alen = nogap ? (int)a->aln_length : aln_path_bytes(a, path);
 	hdr[0] = a->score; memcpy(hdr + 1, &a->L, 8); memcpy(hdr + 3, &a->U, 8);
 	hdr[5] = a->num_mm; hdr[6] = a->num_gapo; hdr[7] = a->num_gape; hdr[8] = alen;
@@ -87,7 +88,7 @@ unsigned char *alns2alnf_buf(const bwb_aln *alns, const uint64_t *aln_off, uint3
 		size_t b = 4;
 		for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; i++) {
 			const bwb_aln *a = &alns[i];
-			const int nogap = a->gap_run[0] == 0xFFFFu && a->gap_run[1] == 0xFFFFu && a->gap_run[2] == 0xFFFFu && a->gap_run[3] == 0xFFFFu;
+			const int nogap = aln_nogap(a);
 			b += (nogap && a->aln_length) ? 44 : aln_rec_bytes(a);
 		}
 		pos[r + 1] = b;
@@ -126,7 +127,8 @@ alns_batch_t *alnsf2alns_bin(const char *alnFname) {
 				bwb_die("alnsf2alns: Could not read ALN file: %s!", alnFname);
 			a->score = (uint16_t)score; a->num_mm = (uint8_t)v[0]; a->num_gapo = (uint8_t)v[1]; a->num_gape = (uint8_t)v[2];
 			a->aln_length = (uint16_t)v[3]; a->reserved = 0;
-			for (int k = 0; k < 4; k++) a->gap_run[k] = 0xFFFF;
+			for (int k = 0; k < BWB_MAX_GAP_RUNS; k++) a->gap_run[k] = 0xFFFF;
+			a->reserved2 = 0;
 			/* The reference loader fills aln_path in PAIR order (align.c:466-476), i.e. the loaded path is the
 			 * align-time path reversed (pairs were written from index aln_length-1 down to 0, align.c:363-373);
 			 * eval_aln / print_aln2sam work on that orientation, so the gap runs are rebuilt the same way. */
@@ -135,7 +137,7 @@ alns_batch_t *alnsf2alns_bin(const char *alnFname) {
 			int pos = 0, nrun = 0;
 			for (int k = 0; k < pairs; k++) {
 				const int st = pp[k] & 3, cnt = pp[k] >> 2;
-				if (st != 0 && nrun < 4) a->gap_run[nrun++] = (uint16_t)((pos & 0xFF) | ((cnt & 0x7F) << 8) | (st == 2 ? 0x8000 : 0));
+				if (st != 0 && nrun < BWB_MAX_GAP_RUNS) a->gap_run[nrun++] = (uint16_t)((pos & 0xFF) | ((cnt & 0x7F) << 8) | (st == 2 ? 0x8000 : 0));
 				pos += cnt;
 			}
 			free(pp);

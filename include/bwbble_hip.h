@@ -38,16 +38,18 @@ typedef struct {
 	int32_t matched_Ncontig, use_precalc, is_multiref, n_threads;
 } bwb_params;
 
-/* One alignment hit = one aln_t (mg-aligner/align.h:81-90) in fixed 32-byte form.
- * The edit path is all STATE_M except for <=4 gap runs (one per gap open):
+/* One alignment hit = one aln_t (mg-aligner/align.h:81-90) in fixed 48-byte form (ABI version 3; 32 bytes with four runs before).
+ * The edit path is all STATE_M except for <= 8 gap runs (one per gap open: -o up to 8):
  * run = start_index_in_path | (run_length << 8) | (is_deletion << 15); unused runs are 0xFFFF. */
+#define BWB_MAX_GAP_RUNS 8
 typedef struct {
 	uint64_t L, U;           /* SA interval */
 	uint16_t score;          /* aln_t.score: the full int aln_score(num_mm, num_gapo, num_gape) (inexact_match.c:332,348); up to 1 024 heap
 	                            buckets are accepted, so it does not fit the 8 bits it had in ABI version 1 */
 	uint8_t num_mm, num_gapo, num_gape, reserved;
 	uint16_t aln_length;     /* 8-bit wrapped like aln_entry_t.aln_length (align.h:104) */
-	uint16_t gap_run[4];
+	uint16_t gap_run[BWB_MAX_GAP_RUNS];
+	uint64_t reserved2;      /* (zero; the record is three 16-byte words) */
 } bwb_aln;
 
 /* Results of one batch: read r owns alns[aln_off[r] .. aln_off[r+1]) in discovery order
@@ -82,9 +84,9 @@ typedef struct {
 
 typedef struct bwb_hip_ctx bwb_hip_ctx;
 
-/* Version of this interface: 2 since bwb_aln.score is 16 bits wide (round 4).  A binding compiled against another version must not
+/* Version of this interface: 3 since bwb_aln holds eight gap runs in 48 bytes (round 5; 2: bwb_aln.score 16 bits wide, round 4).  A binding compiled against another version must not
  * be used with the library: compare BWB_HIP_ABI_VERSION with bwb_hip_abi_version() at start-up. */
-#define BWB_HIP_ABI_VERSION 2
+#define BWB_HIP_ABI_VERSION 3
 int bwb_hip_abi_version(void);
 
 int bwb_hip_device_count(void);

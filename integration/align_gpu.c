@@ -44,7 +44,7 @@ static void add_bwb_aln(alns_t *alns, const bwb_aln *a, const aln_params_t *para
 	aln_entry_t e;
 	memset(&e, 0, sizeof(e));
 	e.num_mm = a->num_mm; e.num_gapo = a->num_gapo; e.num_gape = a->num_gape; e.aln_length = a->aln_length;
-	for (int k = 0; k < 4; k++) {
+	for (int k = 0; k < BWB_MAX_GAP_RUNS; k++) {
 		const unsigned run = a->gap_run[k];
 		if (run == 0xFFFFu) continue;
 		memset(e.aln_path + (run & 0xFF), (run >> 15) ? STATE_D : STATE_I, (run >> 8) & 0x7F);

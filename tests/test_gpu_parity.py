@@ -119,6 +119,23 @@ def test_scores_above_255_match_reference(toy_ctx, golden):
     assert bw.aln_bytes(off, alns) == open(os.path.join(golden, "himm_n5bigpen.aln"), "rb").read()
 
 
+@pytest.mark.parametrize("aln,flags", [("gapo_o5.aln", ["-n", "5", "-o", "5", "-e", "2"]), ("gapo_o6.aln", ["-n", "6", "-o", "6", "-e", "6", "-m", "200000"])])
+def test_more_than_four_gap_opens_match_reference(toy_ctx, oracle, golden, aln, flags):
+    """-o 5 and -o 6 (round 5, ABI version 3: a heap entry and a bwb_aln hold eight gap runs): reads with 2..6 single-base insertions or
+    deletions, whose best alignments open that many gaps - byte-identical to the REAL reference (tests/golden/make_golden.py round5),
+    work counters equal to the oracle's; -o 9 is refused."""
+    seqs, lens = bw.encode_reads(bw.read_fastq(os.path.join(golden, "gapo.fq")))
+    off, alns = toy_ctx.align(bw.params(flags), seqs, lens)
+    assert bw.aln_bytes(off, alns) == open(os.path.join(golden, aln), "rb").read()
+    assert int(alns["num_gapo"].max()) >= 5
+    idx = oracle.load_index(os.path.join(golden, "toy.fa.bwt"))
+    _, ost, _ = oracle.align_encoded(idx, seqs, lens, oracle.params(flags))
+    st = toy_ctx.stats()
+    assert st.heap_pops == ost.heap_pops and st.heap_pushes == ost.heap_pushes and st.visits_single + st.visits_alphabet == ost.visits_single + ost.visits_alphabet
+    with pytest.raises(bw.BwbError):
+        toy_ctx.align(bw.params(["-n", "9", "-o", "9"]), seqs[:1], lens[:1])
+
+
 def test_penalty_and_score_range_limits(toy_ctx, oracle, golden):
     """Score ranges beyond round 2's 128 heap buckets work (bucket-state rows are sized by the range: here (n+1) M + 2 O + 7 E = 320
     buckets) and equal the oracle.  Penalties above 63 (round 5): a child's bucket can lie beyond the 64-bucket window of the non-empty

@@ -426,7 +426,7 @@ def test_bwt_loader_refuses_an_inconsistent_header(built, golden, tmp_path):
         assert r.returncode != 0 and "load_bwt" in r.stdout, (field, r.returncode, r.stdout[-200:])
 
 
-@pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln"])
+@pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln", "gapo_o6.aln"])
 def test_aln_reader_and_writer_round_trip(built, golden, tmp_path, aln):
     """host/aln_io.c without a GPU.  The reference's loader fills aln_path in pair order (align.c:466-476), i.e. it holds the
     align-time path reversed - eval_aln and the CIGAR code work on that orientation (align.c:588-609) and so does ours.  So
@@ -463,15 +463,13 @@ def test_interleave_helper_runs_the_command_or_says_why_not():
     assert subprocess.run([exe], capture_output=True).returncode == 2
 
 
-@pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln", "gapo_o5.aln", "himm_n5bigpen.aln", "sim_chr21_N100_n2.aln"])
+@pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln", "gapo_o5.aln", "gapo_o6.aln", "himm_n5bigpen.aln", "sim_chr21_N100_n2.aln"])
 @pytest.mark.parametrize("chunk", ["1", "7", "100000"])
 def test_chunk_serialiser_writes_the_record_writers_bytes(built, golden, tmp_path, aln, chunk):
     """host/aln_io.c (round 5): `align` turns a chunk's hits into ONE byte buffer in the GPU worker (alns2alnf_buf, all cores) and the
     ordered writer only writes it; the bytes must be those of the record-by-record writer alns2alnf_bin (align.c:345-382) - all-match paths
     (the fast path), gapped paths with several runs, empty records, scores above 255."""
     one, buf = tmp_path / "one.aln", tmp_path / "buf.aln"
-    if aln == "gapo_o5.aln":  # (more than four gap runs per path: outside bwb_aln until the ABI holds eight runs)
-        pytest.skip("gapo_o5.aln has paths with five gap runs; bwb_aln holds four")
     run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(one)])
     run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(buf), "buf", chunk])
     assert open(buf, "rb").read() == open(one, "rb").read()
