@@ -206,9 +206,6 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	/* (Tried, session 12: the loads as structured-buffer loads - record = slice, idle owners out of range, no exec mask, three instructions
 	 * a load instead of nine.  Correct on every test index and wrong at GRCh37 size: without swizzling the range check works on bytes,
 	 * 32 bits of them, and the table has 13.7 GB.) */
-#ifdef BWB_GATHER_PRIO
-	__builtin_amdgcn_s_setprio(0);
-#endif
 	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the slices have landed in LDS - and so has every other load issued before them (the per-position
 	                                       record, the heap entry a pop uncovered, the next list interval: all issued ahead of the gather) */
 	asm volatile("" ::: "memory");
@@ -439,13 +436,43 @@ template <> struct IntvRegs<uint64_t> {
 	static __device__ __forceinline__ void fetch(W &d, const Intv<uint64_t> *p, unsigned long long m) { prefetch128(d, p, m); }
 	static __device__ __forceinline__ uint64_t lo(const W w) { return ((uint64_t)w.y << 32) | w.x; }
 	static __device__ __forceinline__ uint64_t hi(const W w) { return ((uint64_t)w.w << 32) | w.z; }
+	static __device__ __forceinline__ W make(uint64_t L, uint64_t U) { return W{ (uint32_t)L, (uint32_t)(L >> 32), (uint32_t)U, (uint32_t)(U >> 32) }; }
 };
 template <> struct IntvRegs<uint32_t> {
 	typedef u32x2 W;
 	static __device__ __forceinline__ void fetch(W &d, const Intv<uint32_t> *p, unsigned long long m) { prefetch64(d, p, m); }
 	static __device__ __forceinline__ uint32_t lo(const W w) { return w.x; }
 	static __device__ __forceinline__ uint32_t hi(const W w) { return w.y; }
+	static __device__ __forceinline__ W make(uint32_t L, uint32_t U) { return W{ L, U }; }
 };
+/* kl_calc_d's list being built: finished intervals are collected FOUR AT A TIME and stored as one aligned group (round 5: a 16-byte store
+ * is a 32-byte write request to the memory fabric, 12 G of them per launch at GRCh37 scale; back-to-back stores into one 64-byte line merge) */
+template <typename P> struct ListBuf { typename IntvRegs<P>::W b0, b1, b2, b3; };
+template <typename P> __device__ __forceinline__ void list_store_group(const ListBuf<P> &wb, Intv<P> *buf, int t) { /* the group that holds interval t */
+	typedef typename IntvRegs<P>::W W;
+	W *g = (W *)(buf + (t & ~3));
+	g[0] = wb.b0; g[1] = wb.b1; g[2] = wb.b2; g[3] = wb.b3;
+}
+template <typename P> __device__ __forceinline__ void list_add_buf(ListW<P> &l, ListBuf<P> &wb, Intv<P> *base, int sel, P L, P U, int cap) {
+	typedef IntvRegs<P> IR;
+	const bool has = l.T != 0;
+	const bool merge = has && L == (P)(l.tU + 1);
+	const bool flush = has && !merge;
+	const int t = l.T - 1, q = t & 3;
+	const typename IR::W v = IR::make(l.tL, l.tU);
+	wb.b0 = (flush && q == 0) ? v : wb.b0; wb.b1 = (flush && q == 1) ? v : wb.b1;
+	wb.b2 = (flush && q == 2) ? v : wb.b2; wb.b3 = (flush && q == 3) ? v : wb.b3;
+	if (flush && q == 3) list_store_group<P>(wb, base + sel * cap, t);
+	const bool first = flush && l.T == 1;
+	l.fL = first ? l.tL : l.fL; l.fU = first ? l.tU : l.fU;
+	l.tL = merge ? l.tL : L;
+	l.tU = U;
+	l.T += merge ? 0 : 1;
+}
+/* the position is finished: the intervals of the last, incomplete group go to memory (indices 0 .. T-2 are the finished ones) */
+template <typename P> __device__ __forceinline__ void list_flush_buf(const ListW<P> &l, const ListBuf<P> &wb, Intv<P> *base, int sel, int cap) {
+	if (l.T >= 2 && ((l.T - 2) & 3) != 3) list_store_group<P>(wb, base + sel * cap, l.T - 2);
+}
 
 /* ============================================================================================
  * k_calc_d (one read per lane)
@@ -483,6 +510,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 	int c = 4, cnext = 4; /* seq[r] and seq[r - 1]: loaded once per position, one position ahead (round 2 loaded seq[r] in every iteration) */
 	P cL = 0, cU = 0; /* tail (last interval) of the current list */
 	ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
+	ListBuf<P> wb; wb.b0 = wb.b1 = wb.b2 = wb.b3 = typename IntvRegs<P>::W{};
 	int32_t nm = 0, prev_nm = 0;
 	uint32_t bacc = 0, cntN = 0; /* (bacc: the bases of the record being filled) */
 	unsigned long long vis = 0;
@@ -566,13 +594,14 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 				P L, U;
 				kid_get<P>(kc, sb, j, L, U);
 				nm += (int32_t)(uint32_t)(U - L + 1);
-				list_add<P>(nx, lbase, cursel ^ 1, L, U, cap);
+				list_add_buf<P>(nx, wb, lbase, cursel ^ 1, L, U, cap);
 			}
 			s++;
 		}
 		if (ovf) { b.status[rid] = ST_D_OVF; active = false; nxi_valid = false; continue; }
 		if (c > 3 || s >= curT) {
 			/* position finished: swap lists (inexact_match.c:234-237) */
+			if (c <= 3) list_flush_buf<P>(nx, wb, lbase, cursel ^ 1, cap);
 			cursel ^= 1;
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
 			if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers - list_add -, not from what this step has just stored) */
@@ -1020,8 +1049,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	 * (tools/bbprof.py), each a round trip to the scalar cache in the path of a whole wave.  A value it cannot see through is kept, or parked
 	 * in a VGPR lane and fetched with one v_readlane. */
 	KParams kq = kp;
+#ifndef BWB_NO_KQ
 	asm volatile("" : "+s"(kq.max_diff), "+s"(kq.max_gapo), "+s"(kq.max_gape), "+s"(kq.max_entries), "+s"(kq.mm_score), "+s"(kq.gapo_score), "+s"(kq.gape_score));
 	asm volatile("" : "+s"(kq.seed_length), "+s"(kq.max_diff_seed), "+s"(kq.max_best), "+s"(kq.no_indel_length), "+s"(kq.num_buckets), "+s"(kq.use_precalc));
+#endif
 	const int nb = kq.num_buckets;
 	const uint4 *__restrict__ buckets = ix.buckets;
 	const P last_row = (P)(ix.length - 1);
@@ -1258,9 +1289,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		};
 
 		STAMP(0);
-#if defined(BWB_GATHER_PRIO) && BWB_GATHER_PRIO == 2
-		__builtin_amdgcn_s_setprio(3);
-#endif
 		/* ---- A: pick the SA interval of this iteration ---- */
 		/* (Flat on purpose: with 64 reads per wave every path below is taken by some lane in nearly every iteration - tools/bbprof.py counts
 		 * 0.99 executions per wave iteration for all of them - so a nest of branches buys nothing and costs, per level, the scalar mask
@@ -1319,9 +1347,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		HISTW(H_WAVE_ALL_EXACT, __all(!active || exact_mode) ? 1 : 0);
 #endif
 		STAMP(1);
-#if defined(BWB_GATHER_PRIO) && BWB_GATHER_PRIO == 1
-		__builtin_amdgcn_s_setprio(3);
-#endif
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
 		uint32_t wd = 0, ws = 0, ne = 0;
 		int cr = 4, nvis = 0;
