@@ -218,7 +218,7 @@ class Context:
         n = r.n_reads
         off = np.ctypeslib.as_array(r.aln_off, shape=(n + 1,)).copy()
         total = int(off[n])
-        alns = np.frombuffer(C.string_at(r.alns, total * 32), dtype=ALN_DTYPE) if total else np.zeros(0, dtype=ALN_DTYPE)
+        alns = np.frombuffer(C.string_at(r.alns, total * ALN_DTYPE.itemsize), dtype=ALN_DTYPE) if total else np.zeros(0, dtype=ALN_DTYPE)
         return off, alns
 
     def align(self, p, seqs, lens):
