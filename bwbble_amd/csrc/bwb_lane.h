@@ -348,11 +348,25 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 			}
 			if (first + NU >= pi.nU) break;
 		}
-		/* non-empty children, when both positions have the same base row: relU > relL (slice k holds the codes 4k .. 4k+3) */
+		/* non-empty children, when both positions have the same base row: relU > relL (slice k holds the codes 4k .. 4k+3).  The mask is shifted
+		 * in from the top, one code per compare + add-with-carry (ne = 2 ne + [relU > relL]), three compares in flight so that no consumer
+		 * follows its producer by less than the two wait states a VALU-written scalar needs on gfx950: 32 instructions and no s_nop where the
+		 * compiler's compare / select / or (and its nops) took about fifty */
 #pragma unroll
-		for (int k = 0; k < 4; k++) {
+		for (int k = 3; k >= 0; k--) {
 			const u32x4 l = *row_slice(ownR, (uint32_t)k << 4), q = *row_slice(ownR, (uint32_t)(4 + k) << 4);
-			ne |= (q.x > l.x ? 1u : 0u) << (4 * k) | (q.y > l.y ? 1u : 0u) << (4 * k + 1) | (q.z > l.z ? 1u : 0u) << (4 * k + 2) | (q.w > l.w ? 1u : 0u) << (4 * k + 3);
+			unsigned long long sa_, sb_, st_;
+			asm("v_cmp_gt_u32_e64 %[sa], %[qw], %[lw]\n\t"
+			    "v_cmp_gt_u32_e64 %[sb], %[qz], %[lz]\n\t"
+			    "v_cmp_gt_u32_e32 vcc, %[qy], %[ly]\n\t"
+			    "v_addc_co_u32_e64 %[ne], %[st], %[ne], %[ne], %[sa]\n\t"
+			    "v_cmp_gt_u32_e64 %[sa], %[qx], %[lx]\n\t"
+			    "v_addc_co_u32_e64 %[ne], %[st], %[ne], %[ne], %[sb]\n\t"
+			    "v_addc_co_u32_e32 %[ne], vcc, %[ne], %[ne], vcc\n\t"
+			    "v_addc_co_u32_e64 %[ne], %[st], %[ne], %[ne], %[sa]"
+			    : [ne] "+v"(ne), [sa] "=&s"(sa_), [sb] "=&s"(sb_), [st] "=&s"(st_)
+			    : [qw] "v"(q.w), [lw] "v"(l.w), [qz] "v"(q.z), [lz] "v"(l.z), [qy] "v"(q.y), [ly] "v"(l.y), [qx] "v"(q.x), [lx] "v"(l.x)
+			    : "vcc");
 		}
 	}
 	const bool rows_differ = need && pi.rowL != pi.rowU;
@@ -1380,11 +1394,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		h.give_back(pf_free);
 		if (want_rec) {
 			/* bytes j, j + 1 of a record's six D bytes are D[i-2], D[i-1] for i = 4 m + j; wd / ws hold them as {D[i-1] low, D[i-2] high} */
-			const int j8 = (widx & 3) * 8;
-			const uint32_t pd = (uint32_t)(((((uint64_t)(rec.y & 0xFFFFu)) << 32) | rec.x) >> j8) & 0xFFFFu;
-			const uint32_t ps = (uint32_t)(((((uint64_t)(rec.w & 0xFFFFu)) << 32) | rec.z) >> j8) & 0xFFFFu;
-			wd = (pd >> 8) | ((pd & 255u) << 8); ws = (ps >> 8) | ((ps & 255u) << 8);
-			const int cf = (int)((rec.y >> (16 + (j8 >> 1))) & 15u); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
+			/* (one v_perm_b32 per pair: byte j + 1 of the eight bytes {rec.y : rec.x} into byte 0, byte j into byte 1, zeros above) */
+			const uint32_t jb = (uint32_t)widx & 3u;
+			const uint32_t sel = jb * 0x101u + 0x0c0c0001u;
+			wd = __builtin_amdgcn_perm(rec.y, rec.x, sel); ws = __builtin_amdgcn_perm(rec.w, rec.z, sel);
+			const int cf = (int)((rec.y >> (16u + 4u * jb)) & 15u); /* rc[widx-1] = complement of seq[len-1-(widx-1)] (io.c:502-504) */
 			cr = cf > 3 ? 4 : 3 - cf;
 		}
 		STAMP(14);
@@ -1519,16 +1533,20 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const uint32_t f_gap = ((uint32_t)e_mm << 8) | ((uint32_t)((e_go + (gap_open ? 1 : 0)) & 255) << 16) | ((uint32_t)((e_ge + (gap_open ? 0 : 1)) & 255) << 24);
 				const uint64_t eruns = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO, eruns2 = ((uint64_t)ERUNS2_HI << 32) | ERUNS2_LO;
 				uint64_t gruns_i, gruns_d, gruns2 = eruns2; /* new run on open (start = aln_length, len 1); len+1 on extend; runs 4..7 (32-byte entries) in gruns2 */
-				if (gap_open) {
+				if (!WIDE) { /* one run at most (max_gapo <= 1: the run opened is run 0, the run extended is run 0): 32-bit arithmetic */
+					const uint32_t run0 = (e.sa >> 10) & 0xFFFFu;
+					gruns_i = gap_open ? ((uint32_t)e_alen | 0x100u) : run0 + 0x100u;
+					gruns_d = gap_open ? ((uint32_t)e_alen | 0x8100u) : run0 + 0x100u;
+				} else if (gap_open) {
 					const int sh = 16 * (e_go & 3);
-					const bool hi4 = WIDE && e_go >= 4; /* (a fifth to eighth gap open: the run goes into the second word pair, an insertion and a deletion alike but for bit 15) */
+					const bool hi4 = e_go >= 4; /* (a fifth to eighth gap open: the run goes into the second word pair) */
 					const uint64_t src = hi4 ? eruns2 : eruns;
 					const uint64_t cleared = src & ~(0xFFFFull << sh);
 					const uint64_t vi = cleared | ((uint64_t)((uint32_t)e_alen | 0x100u) << sh), vd = cleared | ((uint64_t)((uint32_t)e_alen | 0x8100u) << sh);
 					gruns_i = hi4 ? eruns : vi; gruns_d = hi4 ? eruns : vd;
-					if (hi4) gruns2 = vi; /* (deletion: bit 15 of the new run, set where it is emitted: G2D) */
+					if (hi4) gruns2 = vi; /* (the deletion's version: bit 15 of the new run, gruns2_d below) */
 				} else {
-					const bool hi4 = WIDE && e_go - 1 >= 4;
+					const bool hi4 = e_go - 1 >= 4;
 					const uint64_t inc = 0x100ull << (16 * ((e_go - 1) & 3));
 					gruns_i = gruns_d = hi4 ? eruns : eruns + inc;
 					if (hi4) gruns2 = eruns2 + inc;
