@@ -285,6 +285,7 @@ __device__ __forceinline__ constexpr int cslot(int j) { return 4 * ((j & 7) >> 1
 template <typename P> struct KidCtx {
 	RowRef R;              /* the lane's row: relL in slices 0-3, relU in slices 4-7 (code order: slice k = codes 4k .. 4k+3) */
 	Lds<P> baseL, baseU;   /* base-table rows of the two positions */
+	int nvis;              /* rank-block visits of the pair by the SURVEY 8(d) rule: a position that is neither -1 nor length-1 counts one */
 	bool qL, qU;           /* O_alphabet's view of the codes 5, 9, 11, 13 applies to this side: value = C[j] - [first char of the block == j] */
 };
 /* child j = [vL(j) + 1, vU(j)] */
@@ -318,6 +319,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 	wave_gather<P, NU>(buckets, pi, 0, stage, lane);
 	const RowRef ownR = row_ref(stage, (uint32_t)lane), zeroR = (uint32_t)(uintptr_t)zero_row;
 	kc.R = ownR;
+	kc.nvis = need ? (pi.regL ? 1 : 0) + (pi.regU ? 1 : 0) : 0;
 	kc.qL = alpha && pi.regL; kc.qU = alpha && pi.regU;
 	/* (qL / qU imply a superblock row, 0 .. BWB_NSB_MAX - 1: the second table has just those) */
 	kc.baseL = s_base + pi.rowL * 16 + (kc.qL ? BWB_BASE_ROWS * 16 : 0); kc.baseU = s_base + pi.rowU * 16 + (kc.qU ? BWB_BASE_ROWS * 16 : 0);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 		if (!active) { nxi_valid = false; continue; }
 		bool ovf = false;
 		if (c <= 3) {
-			r_vis += (pi_regular(last_row, (P)(iL - 1)) ? 1 : 0) + (pi_regular(last_row, iU) ? 1 : 0);
+			r_vis += (uint32_t)kc.nvis;
 			ne &= kp.multiref ? member_mask(c) : single_mask_codes(c); /* -S: the base's own code only (inexact_match.c:176-206) */
 			if (list_full<P>(nx, cap)) { ovf = true; ne = 0; }
 			while (ne) { /* children in ascending code order == nucl_bases_table order (io.h:102-106) */
@@ -1311,7 +1313,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const bool popping = active && !exact_mode;
 		const bool can_pop = popping && !(h.num_entries == 0 || h.num_entries > kq.max_entries); /* :293,299 */
 		if (can_pop) {
-			h.switch_cache(h.best(nb));
+			if (!(h.neW & 1ull)) h.switch_cache(h.best(nb)); /* (bit 0 of the window = the cached bucket: still non-empty in all but a few dozen pops per read) */
 #ifdef BWB_HIST
 			h_mirror = h.top_valid;
 #endif
@@ -1363,7 +1365,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		STAMP(1);
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
 		uint32_t wd = 0, ws = 0, ne = 0;
-		int cr = 4, nvis = 0;
+		int cr = 4;
 		const unsigned long long rmask = __ballot(need_rank);
 		const int nreq = __popcll(rmask);
 		const bool want_rec = need_rank || (from_pop && rd_len < kq.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
@@ -1381,14 +1383,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				prefetch128(rec, rb + REC_BYTES * (widx >> 2), mr);
 			}
 		}
-		if (want_rec) {
-			const P pl = (P)(iL - 1);
-			nvis = !need_rank ? 0 : ((pl == (P)~(P)0 || pl == last_row) ? 0 : 1) + ((iU == last_row) ? 0 : 1);
-		}
 		STAMP(2);
 		HISTW(H_WAVE_NREQ_LE16, nreq <= 16 ? 1 : 0);
 		KidCtx<P> kc;
-		kc.R = (uint32_t)(uintptr_t)stage; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false;
+		kc.R = (uint32_t)(uintptr_t)stage; kc.baseL = kc.baseU = sb; kc.qL = kc.qU = false; kc.nvis = 0;
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: the record, LHeap::prefetch) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);
@@ -1475,7 +1473,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (do_expand) {
 			STAMP(8);
 			/* ---- expansion :377-504 ---- */
-			r_vis_a += nvis;
+			r_vis_a += (uint32_t)kc.nvis;
 			bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
 			if (e_i - 1 > 0) {
 				const int d1 = wd & 255u, d2 = (wd >> 8) & 255u;
@@ -1647,7 +1645,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			uint32_t lastW = 0; /* summed width of the list that the step just completed */
 			{ /* (selects, not a nest: one divergent region - the appends - per step) */
 				const bool isN = cr > 3; /* N in the read: exact_match.c:84-87 */
-				if (!isN && !seeding) r_vis_s += nvis; /* (the reference reads the list from its table) */
+				if (!isN && !seeding) r_vis_s += (uint32_t)kc.nvis; /* (the reference reads the list from its table) */
 				uint32_t nm = isN ? 0u : (ne & (MULTI ? member_mask(cr) : 2u << cr));
 				if (!isN && list_full<P>(nx, lcap)) { ovf = true; nm = 0; }
 				while (nm) { /* ascending code order == nucl_bases_table order (io.h:102-106) */

@@ -7,15 +7,18 @@
 #   4. the same command under rocprofv3 --kernel-trace --stats (3 steps) -> r5_c3_kernel_stats.csv, r5_c3_kernel_launches.json + the line it printed
 #   5. SQ counters of kl_search (tools/pmc_mem.sh, the SQ groups) and the TLB group
 #   6. basic-block profile of the shipped kernels (tools/bbprof.py)
-#   7. config C5: PMC traffic + bench line; config C2: bench line
+#   7. config C5: PMC traffic + bench line (and once with three blocks per CU forced: what VERDICT r4's item 2 is about); config C2: bench line
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r5final; mkdir -p $O
 cd $R
-( time timeout 1800 python3 -m pytest tests -m gpu -x -q -s ) > $O/pytest.log 2>&1; echo "pytest exit $?"; grep -h "grch37\|passed\|failed\|skipped\|real" $O/pytest.log | tail -8
+( time timeout 1800 python3 -m pytest tests -m gpu -x -q -s ) > $O/pytest.log 2>&1; PRC=$?; echo "pytest exit $PRC"; grep -h "grch37\|passed\|failed\|skipped\|real" $O/pytest.log | tail -8
+if [ $PRC -ne 0 ]; then tail -40 $O/pytest.log; echo "GPU tests failed: no evidence is taken on kernels that are not green"; exit 1; fi
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
 cd /tmp && export TMPDIR=/tmp
+# (one more A/B line for profiles/r5_ab_steps.txt: session 7's product against HEAD)
+bash $R/tools/ab_bench.sh r5final_ab "--steps 6 --warmup 2 --no-extras" s7:bwbble_amd/tools_exp/libbwbble_hip_s7.so product > $O/ab.txt 2>&1; cat $O/ab.txt
 bash $R/tools/pmc_traffic.sh r5_c3 > $O/pmc_c3.log 2>&1; tail -3 $O/pmc_c3.log; cp $R/gpurun_out/r5_c3_pmc.json $R/profiles/r5_c3_pmc.json 2>/dev/null   # (so that the bench line below can quote it)
-( time timeout 3000 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_args.log 2> $O/bench_driver_args.err
+( export BWB_BENCH_BUDGET_S=5000; time timeout 3000 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_args.log 2> $O/bench_driver_args.err
 grep '^{"metric"' $O/bench_driver_args.log > $O/r5_bench_line_driver_args.json; tail -3 $O/bench_driver_args.err | cut -c1-200
 python3 $R/tools/ab_show.py c3_driver_args < $O/r5_bench_line_driver_args.json
 ( time timeout 900 python3 $R/tools/cli_check.py /tmp/bwb_bench/genome_3100000000.fa /tmp/bwb_bench/reads_3100000000_10000000_100_i0.1_r0.fq 5000 -n 3 ) > $O/r5_cli_c3.txt 2>&1; tail -6 $O/r5_cli_c3.txt
@@ -30,5 +33,6 @@ PMC_SETS="1 5 6 7" bash $R/tools/pmc_mem.sh 3100 10000000 2500000 3 > $O/pmc_mem
 python3 $R/tools/bbprof.py report $O/bb_counts.json > $O/r5_bbprof_final.txt 2>&1; head -4 $O/r5_bbprof_final.txt
 bash $R/tools/pmc_traffic.sh r5_c5 --config C5 > $O/pmc_c5.log 2>&1; tail -3 $O/pmc_c5.log; cp $R/gpurun_out/r5_c5_pmc.json $R/profiles/r5_c5_pmc.json 2>/dev/null
 timeout 2400 python3 $R/bench.py --config C5 --steps 20 --warmup 5 --no-extras > $O/r5_bench_line_c5.json 2> $O/c5.err; python3 $R/tools/ab_show.py c5 < $O/r5_bench_line_c5.json
+BWB_BLOCKS_PER_CU=3 timeout 1500 python3 $R/bench.py --config C5 --steps 10 --warmup 2 --no-extras > $O/r5_bench_line_c5_three_blocks.json 2> $O/c5b3.err; python3 $R/tools/ab_show.py c5_three_blocks < $O/r5_bench_line_c5_three_blocks.json
 timeout 1200 python3 $R/bench.py --config C2 --steps 20 --warmup 5 --no-extras > $O/r5_bench_line_c2.json 2> $O/c2.err; python3 $R/tools/ab_show.py c2 < $O/r5_bench_line_c2.json
 ls $O
