@@ -936,10 +936,16 @@ template <typename P, bool WIDE> struct LHeap {
 	/* issues what pop() asked for (every lane of the wave calls this, in uniform control flow) */
 	__device__ __forceinline__ void prefetch(uint32_t pf_top, uint32_t pf_hdr) {
 		const unsigned long long mt = __ballot(pf_top != NONE32), mh = __ballot(pf_hdr != NONE32);
-		if (mt) {
-			const uint4 *src = pool + (size_t)pf_top * (WIDE ? 2 : 1); /* (a state word is the slot's index in the pool) */
-			prefetch128(tw, src, mt);
-			if (WIDE) prefetch128(tw1, src + 1, mt);
+		{ /* (not under `if (mt)`: some lane of the wave uncovers an entry in nearly every iteration, and a branch around an in-place load makes
+		   * the compiler merge a loaded and a not-loaded version of the registers behind it; with an empty mask the load is a no-op) */
+#ifdef BWB_COND_PF
+			if (mt)
+#endif
+			{
+				const uint4 *src = pool + (size_t)pf_top * (WIDE ? 2 : 1); /* (a state word is the slot's index in the pool) */
+				prefetch128(tw, src, mt);
+				if (WIDE) prefetch128(tw1, src + 1, mt);
+			}
 		}
 		if (mh) prefetch32(cprev, (const uint32_t *)chunk_ptr(pf_hdr) + 1, mh);
 		/* the new head of the list of emptied chunks, when an allocation of the previous iteration took the old one */
@@ -1377,7 +1383,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		{
 			const unsigned long long mr = __ballot(rec_load);
 			n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(mr)));
-			if (mr) { /* the read's records written by kl_calc_d: 16 bytes per four positions (bwb_kernels.h: rec_put) */
+#ifdef BWB_COND_PF
+			if (mr)
+#endif
+			{ /* the read's records written by kl_calc_d: 16 bytes per four positions (bwb_kernels.h: rec_put); unconditional like LHeap::prefetch */
 				const uint32_t sl_ = rd_myslot;
 				const unsigned char *rb = (const unsigned char *)(uintptr_t)((Lds<unsigned long long>)&s_dbuf[0])[sl_] + (size_t)rid * ((Lds<unsigned int>)&s_dstride[0])[sl_];
 				prefetch128(rec, rb + REC_BYTES * (widx >> 2), mr);
