@@ -41,6 +41,12 @@
 /* lane-private LDS columns: explicit LDS address space, so they compile to ds_read/ds_write (a generic or volatile
  * pointer here turns every access into a flat_* instruction with 64-bit addresses and full waits) */
 template <typename P> using Lds = __attribute__((address_space(3))) P *;
+/* wave votes on a BOOLEAN: the lane mask itself.  HIP's __ballot / __any / __all take an int, and the compiler turns the bool into 0 / 1 in a
+ * vector register and compares it with zero again - two vector instructions and a hazard nop per vote, fourteen votes per iteration of
+ * kl_search (tools/bbprof.py: 22 vector instructions per wave iteration under amd_warp_functions.h / amd_device_functions.h) */
+__device__ __forceinline__ unsigned long long wballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool wany(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+__device__ __forceinline__ bool wall(bool b) { return __builtin_amdgcn_ballot_w64(!b) == 0ull; } /* (over the lanes that execute it: inactive lanes vote 0) */
 #define CHUNK_SLOTS 64          /* slot 0 is the header: 63 entries per chunk */
 #define POOL_REGIONS 8
 #define BSTATE_ROW_MIN 128      /* bucket states per lane (LaneScratch::brow): at least this many, else the score range rounded up to 64 (at most 1024 buckets, bwb_hip.hip check_params) */
@@ -153,7 +159,7 @@ __device__ __forceinline__ void pair_setup(P last_row, bool need, P pL, P pU, in
 	pi.same = need && pi.regL && pi.regU && bL == bU;
 	const bool wantL = need && pi.regL, wantU = need && pi.regU && !pi.same;
 	pi.blkL = wantL ? (uint32_t)bL : NONE32; pi.blkU = wantU ? (uint32_t)bU : NONE32;
-	const unsigned long long maskU = __ballot(wantU);
+	const unsigned long long maskU = wballot(wantU);
 	pi.nU = __popcll(maskU);
 	pi.ku = wantU ? (uint32_t)__popcll(maskU & ((1ull << lane) - 1ull)) : NONE32;
 }
@@ -315,7 +321,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
                                                   Lds<u32x4> stage, Lds<u32x4> zero_row, int lane, uint32_t &n_bkt, KidCtx<P> &kc) {
 	PairInfo<P> pi;
 	pair_setup<P>(last_row, need, (P)(iL - 1), iU, lane, pi);
-	n_bkt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_bkt + (uint32_t)__popcll(__ballot(pi.blkL != NONE32)) + (uint32_t)pi.nU)); /* (wave-uniform: the whole wave's buckets, added up by lane 0 at the end) */
+	n_bkt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_bkt + (uint32_t)__popcll(wballot(pi.blkL != NONE32)) + (uint32_t)pi.nU)); /* (wave-uniform: the whole wave's buckets, added up by lane 0 at the end) */
 	wave_gather<P, NU>(buckets, pi, 0, stage, lane);
 	const RowRef ownR = row_ref(stage, (uint32_t)lane), zeroR = (uint32_t)(uintptr_t)zero_row;
 	kc.R = ownR;
@@ -372,7 +378,7 @@ __device__ __forceinline__ uint32_t wave_children(const uint4 *__restrict__ buck
 		}
 	}
 	const bool rows_differ = need && pi.rowL != pi.rowU;
-	if (__any(rows_differ)) { /* a pair that straddles a superblock boundary or has a special position (the root's -1 / length-1): compare positions */
+	if (wany(rows_differ)) { /* a pair that straddles a superblock boundary or has a special position (the root's -1 / length-1): compare positions */
 		if (rows_differ) {
 			ne = 0;
 #pragma unroll 1
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 				if (!active) { b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = 0; b.status[rid] = ST_OK; }
 			}
 		}
-		if (__all(done)) break;
+		if (wall(done)) break;
 		P iL = 0, iU = 0;
 		/* (the cached group is only ever touched here and by the prefetch below, in straight-line code at the loop's top level: with its uses
 		 * inside the nest of branches the register allocator kept a second copy of it and moved one into the other while the prefetch was in
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 		   * issued now, IN PLACE (prefetch128: nothing looks at g0..g3 before the gather's wait below), and landing under this iteration's
 		   * gather.  The cached group is not needed any more then: the next interval is the first of another group. */
 			const bool want = active && c <= 3 && s + 1 < curT - 1 && ((s + 1) >> 2) != cg;
-			const unsigned long long mw = __ballot(want);
+			const unsigned long long mw = wballot(want);
 			/* (not under `if (mw)`: a branch around the in-place loads makes the compiler merge a loaded and a not-loaded version of the four
 			 * registers behind it - copies of registers that are in flight; with an empty mask the loads are no-ops) */
 			const Intv<P> *g = lbase + cursel * cap + ((s + 1) & ~3);
@@ -935,12 +941,9 @@ template <typename P, bool WIDE> struct LHeap {
 	}
 	/* issues what pop() asked for (every lane of the wave calls this, in uniform control flow) */
 	__device__ __forceinline__ void prefetch(uint32_t pf_top, uint32_t pf_hdr) {
-		const unsigned long long mt = __ballot(pf_top != NONE32), mh = __ballot(pf_hdr != NONE32);
+		const unsigned long long mt = wballot(pf_top != NONE32), mh = wballot(pf_hdr != NONE32);
 		{ /* (not under `if (mt)`: some lane of the wave uncovers an entry in nearly every iteration, and a branch around an in-place load makes
 		   * the compiler merge a loaded and a not-loaded version of the registers behind it; with an empty mask the load is a no-op) */
-#ifdef BWB_COND_PF
-			if (mt)
-#endif
 			{
 				const uint4 *src = pool + (size_t)pf_top * (WIDE ? 2 : 1); /* (a state word is the slot's index in the pool) */
 				prefetch128(tw, src, mt);
@@ -950,7 +953,7 @@ template <typename P, bool WIDE> struct LHeap {
 		if (mh) prefetch32(cprev, (const uint32_t *)chunk_ptr(pf_hdr) + 1, mh);
 		/* the new head of the list of emptied chunks, when an allocation of the previous iteration took the old one */
 		const bool taken = fhead != NONE32 && (fhead & FHEAD_TAKEN) != 0u;
-		const unsigned long long mf = __ballot(taken);
+		const unsigned long long mf = wballot(taken);
 		if (mf) prefetch32(fhead, (const uint32_t *)chunk_ptr(fhead & ~FHEAD_TAKEN), mf);
 	}
 };
@@ -959,7 +962,7 @@ template <typename P, bool WIDE> struct LHeap {
 __device__ __forceinline__ uint32_t wave_sum5(uint32_t v) {
 	uint32_t t = 0;
 #pragma unroll
-	for (int b = 0; b < 5; b++) t += (uint32_t)__popcll(__ballot((v >> b) & 1u)) << b;
+	for (int b = 0; b < 5; b++) t += (uint32_t)__popcll(wballot(((v >> b) & 1u) != 0u)) << b;
 	return t;
 }
 
@@ -987,7 +990,7 @@ __device__ __forceinline__ uint32_t wave_sum5(uint32_t v) {
  * iterations are (expansion / exact step / pruned / hit), how wide the expanded intervals are, how many children they have, what
  * is pushed where.  HIST(k, cond) counts the lanes for which cond holds; HISTW(k, v) adds a wave-uniform value.  Off in the product. */
 #ifdef BWB_HIST
-#define HIST(k, cond) do { hist[k] += (unsigned long long)__popcll(__ballot(cond)); } while (0)
+#define HIST(k, cond) do { hist[k] += (unsigned long long)__popcll(wballot(cond)); } while (0)
 #define HISTW(k, v) do { hist[k] += (unsigned long long)(v); } while (0)
 #else
 #define HIST(k, cond) do { } while (0)
@@ -1184,7 +1187,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				const uint32_t left = used < h.pool_cap ? h.pool_cap - used : 0u;
 				const uint32_t blocks_in_region = (gridDim.x + sc.n_regions - 1) / sc.n_regions;
 				const uint32_t avail = s_nfree + left / blocks_in_region;
-				const uint32_t mine = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
+				const uint32_t mine = __popcll(wballot(true) & ((1ull << lane) - 1ull));
 				/* what a read is expected to take: four times the mean of the reads this block has finished (the needs are heavy-tailed;
 				 * 150 bp reads with -n 5 average 1 750 chunks at GRCh37 scale, 100 bp reads with -n 3 a third of that), at least 1 MB */
 				const uint32_t cnt = s_need_cnt, per = cnt ? (uint32_t)(((unsigned long long)s_need_sum * 64ull) / cnt) : 0u;
@@ -1246,7 +1249,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			}
 		}
 		if (wk.slice_iters && w_iter >= wk.slice_iters) park = true;
-		if (__any(park)) {
+		if (wany(park)) {
 			/* ---- end of the slice for this wave: park the reads under way (word 0 of the save area tells the next launch) ---- */
 			if (active) {
 				__hip_atomic_fetch_add((Lds<unsigned int>)&s_active, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); /* (lanes of other waves may be waiting for admission) */
@@ -1273,8 +1276,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			parked = active;
 			break;
 		}
-		if (__all(done)) break;
-		if (!__any(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
+		if (wall(done)) break;
+		if (!wany(active)) __builtin_amdgcn_s_sleep(64); /* a wave whose lanes all wait for admission */
 
 		bool finish = false, ovf = false, from_pop = false, need_rank = false, alpha = false, is_group = false;
 #ifdef BWB_PERTURB_VALU /* measurement only: what does the loop pay for 128 more vector instructions per iteration? (profiles/r4_ab_steps.txt) */
@@ -1287,7 +1290,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		uint32_t pf_top = NONE32, pf_hdr = NONE32, pf_free = NONE32; /* what LHeap::pop wants fetched ahead of the gather; the chunk it emptied */
 		P iL = 0, iU = 0;
 		int widx = 0;
-		n_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_iter + (uint32_t)__popcll(__ballot(active)))); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
+		n_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_iter + (uint32_t)__popcll(wballot(active)))); /* (wave-uniform, like w_iter and n_bkt: lane 0 reports them) */
 		w_iter = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w_iter + 1u));
 		HIST(H_ITER, active); HISTW(H_WAVE_ITERS, 1);
 #ifdef BWB_HIST
@@ -1364,15 +1367,15 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		HIST(H_SAME_BKT, hsame_); HIST(H_TWO_BKT, need_rank && !hsame_);
 		HIST(H_W1, need_rank && hw_ == 1); HIST(H_W2, need_rank && hw_ == 2); HIST(H_W4, need_rank && hw_ > 2 && hw_ <= 4); HIST(H_W8, need_rank && hw_ > 4 && hw_ <= 8);
 		HIST(H_W32, need_rank && hw_ > 8 && hw_ <= 32); HIST(H_W128, need_rank && hw_ > 32 && hw_ <= 128); HIST(H_WBIG, need_rank && (hw_ > 128 || hw_ == 0));
-		HISTW(H_WAVE_ANY_TWO_BKT, __any(need_rank && !hsame_) ? 1 : 0); HISTW(H_WAVE_ANY_WIDE8, __any(need_rank && (hw_ > 8 || hw_ == 0)) ? 1 : 0);
-		HISTW(H_WAVE_ANY_EXACT, __any(active && exact_mode) ? 1 : 0); HISTW(H_WAVE_ANY_EXPAND, __any(from_pop && need_rank) ? 1 : 0);
-		HISTW(H_WAVE_ALL_EXACT, __all(!active || exact_mode) ? 1 : 0);
+		HISTW(H_WAVE_ANY_TWO_BKT, wany(need_rank && !hsame_) ? 1 : 0); HISTW(H_WAVE_ANY_WIDE8, wany(need_rank && (hw_ > 8 || hw_ == 0)) ? 1 : 0);
+		HISTW(H_WAVE_ANY_EXACT, wany(active && exact_mode) ? 1 : 0); HISTW(H_WAVE_ANY_EXPAND, wany(from_pop && need_rank) ? 1 : 0);
+		HISTW(H_WAVE_ALL_EXACT, wall(!active || exact_mode) ? 1 : 0);
 #endif
 		STAMP(1);
 		/* ---- B: one round of memory: D words, read base, both rank buckets and the side heap buckets, issued together ---- */
 		uint32_t wd = 0, ws = 0, ne = 0;
 		int cr = 4;
-		const unsigned long long rmask = __ballot(need_rank);
+		const unsigned long long rmask = wballot(need_rank);
 		const int nreq = __popcll(rmask);
 		const bool want_rec = need_rank || (from_pop && rd_len < kq.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
 		/* The record of the entry's position (D[i-1], D[i-2] | D_seed pair | seq[len - widx]: bwb_kernels.h) - the one in registers when its tag
@@ -1381,11 +1384,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		 * its gather was even issued, a round trip that the gather's own wait covers for free. */
 		const bool rec_load = want_rec && (rec.w >> 16) != (uint32_t)(widx >> 2);
 		{
-			const unsigned long long mr = __ballot(rec_load);
+			const unsigned long long mr = wballot(rec_load);
 			n_rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n_rec + (uint32_t)__popcll(mr)));
-#ifdef BWB_COND_PF
-			if (mr)
-#endif
 			{ /* the read's records written by kl_calc_d: 16 bytes per four positions (bwb_kernels.h: rec_put); unconditional like LHeap::prefetch */
 				const uint32_t sl_ = rd_myslot;
 				const unsigned char *rb = (const unsigned char *)(uintptr_t)((Lds<unsigned long long>)&s_dbuf[0])[sl_] + (size_t)rid * ((Lds<unsigned int>)&s_dstride[0])[sl_];
