@@ -734,6 +734,7 @@ template <typename P, bool WIDE> struct LHeap {
 	uint32_t stX, stGo, stGe;
 	int pX, pGo, pGe;      /* the three penalties (wave-uniform copies of the kernel parameters) */
 	int nbk;               /* number of buckets: a side bucket beyond the score range does not exist */
+	int pXv, pGov, pGev, nbkv; /* the same four numbers once more, in VECTOR registers, for per-lane arithmetic (the scalar copies decide the wave-uniform branches): see kl_search */
 	int num_entries;
 	/* Register mirror of the TWO entries on top of bucket cb's stack, in the packed form they have in memory (tw: the top - 16 bytes, 32
 	 * when WIDE; sw: the one below it, 16-byte entries only).  Why two, and why packed: a pop takes the top from `tw`; what it uncovers
@@ -764,14 +765,14 @@ template <typename P, bool WIDE> struct LHeap {
 	__device__ __forceinline__ int side_of(int pen) const { return pen == 0 ? 0 : (pen == pX ? 1 : (pen == pGo ? 2 : 3)); }
 	/* the side registers -> memory (when the cached bucket changes, when the read is parked) */
 	__device__ __forceinline__ void side_flush() const {
-		if (pX != 0 && cb + pX < nbk) bstate[cb + pX] = stX;
-		if (side_of(pGo) == 2 && cb + pGo < nbk) bstate[cb + pGo] = stGo;
-		if (side_of(pGe) == 3 && cb + pGe < nbk) bstate[cb + pGe] = stGe;
+		if (pX != 0 && cb + pXv < nbkv) bstate[cb + pXv] = stX;
+		if (side_of(pGo) == 2 && cb + pGov < nbkv) bstate[cb + pGov] = stGo;
+		if (side_of(pGe) == 3 && cb + pGev < nbkv) bstate[cb + pGev] = stGe;
 	}
 	__device__ __forceinline__ void side_load() {
-		stX = (pX != 0 && cb + pX < nbk) ? bstate[cb + pX] : NONE32;
-		stGo = (side_of(pGo) == 2 && cb + pGo < nbk) ? bstate[cb + pGo] : NONE32;
-		stGe = (side_of(pGe) == 3 && cb + pGe < nbk) ? bstate[cb + pGe] : NONE32;
+		stX = (pX != 0 && cb + pXv < nbkv) ? bstate[cb + pXv] : NONE32;
+		stGo = (side_of(pGo) == 2 && cb + pGov < nbkv) ? bstate[cb + pGov] : NONE32;
+		stGe = (side_of(pGe) == 3 && cb + pGev < nbkv) ? bstate[cb + pGev] : NONE32;
 	}
 	/* Penalties above 63 (WIDE instantiation only: the host routes such parameters to the 32-byte-entry kernels, whatever -o is): a child's
 	 * bucket can lie beyond the window.  Such a bucket is simply not marked - its state is in a side register or in memory - and the window
@@ -794,9 +795,9 @@ template <typename P, bool WIDE> struct LHeap {
 		side_flush();
 		/* (the new cached bucket is very often the old mismatch bucket: its state is at hand) */
 		const int d = s - cb;
-		const bool have = d == pX || d == pGo || d == pGe;
+		const bool have = d == pXv || d == pGov || d == pGev;
 		const uint32_t vX = stX, vGo = stGo, vGe = stGe; /* (values first: a conditional between two members is a conditional between two addresses, and keeps the whole struct in memory) */
-		const uint32_t fwd = d == pX ? vX : (d == pGo ? vGo : vGe);
+		const uint32_t fwd = d == pXv ? vX : (d == pGov ? vGo : vGe);
 		neW = (WIDE && far && d >= 64) ? 0ull : neW >> d; /* (s > cb: the cached bucket is empty and nothing lies below it) */
 		cb = s; cst = have ? fwd : bstate[s];
 		if (WIDE && far) { /* buckets that have come into the window's range: their states are in memory (side_flush above) */
@@ -1051,9 +1052,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	if (threadIdx.x < BWB_MAX_SLOTS) { s_dbuf[threadIdx.x] = (unsigned long long)(uintptr_t)descs[threadIdx.x].b.dbuf; s_dstride[threadIdx.x] = descs[threadIdx.x].b.dstride; }
 	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
 	load_base2<P>(s_base, ix);
-	/* The lane's scratch areas are addressed from its slot number where they are used: `slotv` is passed through an empty asm
-	 * statement in every iteration, so the compiler cannot keep six 64-bit pointers alive across the loop (registers are what
-	 * decides whether three waves fit a SIMD). */
+	/* The lane's hit list and save area are addressed from its slot number where they are used (rare paths); its bucket states and its
+	 * lists - every iteration - through pointers that live across the loop (see below). */
 	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
 	uint32_t slotv = slot;
 	/* The bases and sizes of the lane's scratch areas that the loop uses in (almost) every iteration, made OPAQUE scalar values: with more
@@ -1063,8 +1063,14 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	typedef __attribute__((address_space(1))) unsigned char *GlobalBytes; /* (global pointers: a pointer made from an integer would be a flat one) */
 	GlobalBytes sc_lists = (GlobalBytes)sc.lists, sc_alns = (GlobalBytes)sc.alns, sc_bstate = (GlobalBytes)sc.bstate;
 	uint32_t sc_lcap = sc.lcap, sc_acap = sc.acap, sc_brow = sc.brow;
-	asm volatile("" : "+s"(sc_lists), "+s"(sc_alns), "+s"(sc_bstate), "+s"(sc_lcap), "+s"(sc_acap), "+s"(sc_brow));
-#define lbase ((Intv<P> *)(unsigned char *)sc_lists + (size_t)slotv * 2 * sc_lcap)
+	/* (round 5) ... and held in VECTOR registers: the loop has more wave-uniform values than scalar registers, the compiler parks the loop
+	 * invariants among them in lanes of a VGPR and fetches them with a v_readlane (+ hazard nops) in front of every use - 300 of them in the
+	 * loop's code; the kernel needs 152 of the 168 vector registers that three waves per SIMD allow, so the invariants that only per-lane
+	 * arithmetic reads live in the sixteen spare ones, where a vector instruction reads them for nothing.  The addresses of the lane's
+	 * bucket states and lists are kept as pointers for the same reason (rounds 3-4 rebuilt them from the slot number where they were used,
+	 * when registers were short): loop 5 613 -> 5 251 instructions, 299 -> 96 v_readlane, 87 -> 36 s_nop. */
+	asm volatile("" : "+v"(sc_lists), "+v"(sc_alns), "+v"(sc_bstate), "+v"(sc_lcap), "+v"(sc_acap), "+v"(sc_brow));
+	Intv<P> *const lbase = (Intv<P> *)(unsigned char *)sc_lists + (size_t)slotv * 2 * sc_lcap;
 #define myalns ((uint4 *)(unsigned char *)sc_alns + (size_t)slotv * sc_acap * ALN_U4)
 #define mysave (R_sc(save) + (size_t)slotv * SAVE_U4)
 	auto xs = [&]() -> uint32_t * { return (uint32_t *)(mysave + 15); }; /* the tail and the length of the lane's excess chain (LHeap::alloc) */
@@ -1089,6 +1095,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	h.pool = sc.pool + (size_t)region * sc.region_u4; h.pool_bump = sc.pool_bump + region * 16; h.pool_cap = sc.pool_cap; h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow; h.nslots = sc.nslots;
 	h.xhead = NONE32; h.nfree = (Lds<unsigned int>)&s_nfree; h.keep = sc.keep; h.blockfree = (Lds<unsigned long long>)&s_blockfree;
 	h.pX = kq.mm_score; h.pGo = kq.gapo_score; h.pGe = kq.gape_score; h.nbk = nb;
+	h.pXv = h.pX; h.pGov = h.pGo; h.pGev = h.pGe; h.nbkv = nb;
+	if (!WIDE) asm volatile("" : "+v"(h.pXv), "+v"(h.pGov), "+v"(h.pGev), "+v"(h.nbkv)); /* (the 32-byte-entry kernels have no registers to spare: there these stay scalars) */
 	h.far = WIDE && (kq.mm_score > 63 || kq.gapo_score > 63 || kq.gape_score > 63);
 	h.fhead = NONE32;
 	h.reset();
@@ -1175,8 +1183,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 	for (;;) {
 		STAMP(7);
-		asm volatile("" : "+v"(slotv));
-		h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow;
 		bool admit = !active && !done;
 		if (admit) {
 			/* admission: what a read will need is not known in advance, and a read that finds the pool empty is given up and
@@ -1334,7 +1340,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			const bool grp = can_pop && (e.sa & 3u) == (uint32_t)STATE_GROUP;
 			/* :309 (the reference pops that child, then stops).  aln_entry_t.score is an 8-bit field (align.h:104): what the reference compares is
 			 * the score modulo 256 - the same number unless the parameters allow scores above 255 */
-			const bool over = can_pop && (e_score & 255) > rd_best_score + kq.mm_score;
+			const bool over = can_pop && (e_score & 255) > rd_best_score + h.pXv;
 			finish = popping && (!can_pop || over);
 			r_pop += (can_pop && (!grp || over)) ? 1u : 0u;
 			from_pop = can_pop && !over;
@@ -1409,11 +1415,9 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			cr = cf > 3 ? 4 : 3 - cf;
 		}
 		STAMP(14);
-		asm volatile("" : "+v"(slotv));
-		h.bstate = (uint32_t *)(unsigned char *)sc_bstate + (size_t)slotv * sc_brow;
 		/* heap buckets an expansion of this entry can push to besides its own: mismatch, gap (:434-504); their states are in registers (LHeap) */
 		const int e_state = (int)(e.sa & 3u);
-		const int scX = e_score + kq.mm_score, scG = e_score + (e_state == STATE_M ? kq.gapo_score : kq.gape_score);
+		const int scX = e_score + h.pXv, scG = e_score + (e_state == STATE_M ? h.pGov : h.pGev);
 		const int wG = e_state == STATE_M ? h.side_of(kq.gapo_score) : h.side_of(kq.gape_score); /* which register is the gap bucket's (0: the cached bucket itself) */
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
@@ -1830,7 +1834,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	}
 }
 
-#undef lbase
 #undef ERUNS_LO
 #undef ERUNS_HI
 #undef ERUNS2_LO
