@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 5, session 9: parity tests; basic-block profile of the product; A/B at C3: s8 (session 8's product) | product (loop invariants of per-lane
+# arithmetic in spare vector registers, bucket-state and list pointers live across the loop); product with the driver's 20 steps.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT=$R
+cd $R
+O=$R/gpurun_out/r5s9; mkdir -p $O
+( time timeout 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_zz_grch37.py --deselect tests/test_gpu_fullsize.py ) > $O/tests.txt 2>&1
+tail -5 $O/tests.txt
+cd /tmp && export TMPDIR=/tmp
+bash $R/tools/ab_bench.sh r5s9 "--steps 6 --warmup 2 --no-extras" s8:bwbble_amd/tools_exp/libbwbble_hip_s8.so product s8b:bwbble_amd/tools_exp/libbwbble_hip_s8.so product2 > $O/ab.txt 2>&1
+cat $O/ab.txt
+( export BWB_LIB=$R/bwbble_amd/tools_exp/libbwbble_hip_bbprof.so BWB_BBPROF_OUT=$O/bb_counts.json
+  timeout 900 python3 $R/bench.py --steps 3 --warmup 0 --reads 1000000 --no-extras > $O/bb_bench.json 2> $O/bb_bench.err ); echo "bbprof rc $?"
+python3 $R/tools/bbprof.py report $O/bb_counts.json > $O/bb_report.txt 2>&1; head -12 $O/bb_report.txt
+bash $R/tools/ab_bench.sh r5s9_20 "--steps 20 --warmup 2 --no-extras" product > $O/ab20.txt 2>&1
+cat $O/ab20.txt
