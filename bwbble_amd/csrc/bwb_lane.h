@@ -182,11 +182,14 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	const bool mineU = pi.ku != NONE32 && (int)pi.ku >= first && (int)pi.ku < first + NU;
 	const uint32_t k = pi.ku - (uint32_t)first;
 	/* (the exchange array carries bucket << 3, the bucket's index in 16-byte slices - one add and one shift-add make the address; a bucket
-	 * number has 28 bits, NONE32 stays NONE32) */
-	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? NONE32 : pi.blkL << 3;
-	xch[64 + lane] = NONE32;
+	 * number has 28 bits.  An owner with nothing to fetch publishes bucket 0: every lane then loads in every instruction, with no exec mask
+	 * to narrow and restore - compare, s_and_saveexec, branch and s_or were four of the nine instructions of a load, eleven times per
+	 * iteration (tools/bbprof.py).  The idle slots' 128 bytes are one hot line of the L1; they land in rows that nobody reads: the row of a
+	 * lane without a request, or a U row beyond the wave's count.) */
+	if (first == 0) xch[(lane & 7) * 8 + (lane >> 3)] = pi.blkL == NONE32 ? 0u : pi.blkL << 3;
+	xch[64 + lane] = 0u;
 	if (mineU) xch[64 + (k & 7) * 8 + (k >> 3)] = pi.blkU << 3;
-	u32x4 a0 = { NONE32, NONE32, NONE32, NONE32 }, a1 = a0;
+	u32x4 a0 = { 0u, 0u, 0u, 0u }, a1 = a0;
 	if (first == 0) { a0 = ((Lds<u32x4>)xch)[sub * 2]; a1 = ((Lds<u32x4>)xch)[sub * 2 + 1]; }
 	const u32x4 b0 = ((Lds<u32x4>)xch)[16 + sub * 2];
 	__builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the owners are in registers, and whatever was read from the rows before (the children of
@@ -198,16 +201,19 @@ __device__ __forceinline__ void wave_gather(const uint4 *__restrict__ buckets, c
 	/* slice of instruction r = p ^ rot(8 r + sub) = p ^ ((sub >> 1) + 4 (r & 1)) = p ^ (sub >> 1) ^ 4 (r & 1): two values, for even and for odd r */
 	const uint32_t sl0 = (uint32_t)(p ^ (sub >> 1)), sl1 = sl0 ^ 4u;
 	const uint32_t oL[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+	if (first == 0) {
 #pragma unroll
-	for (int r = 0; r < 8; r++) {
-		const uint32_t slice = (r & 1) ? sl1 : sl0;
-		if (oL[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
+		for (int r = 0; r < 8; r++) {
+			const uint32_t slice = (r & 1) ? sl1 : sl0;
+			__builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oL[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 1024u * r), 16, 0, BWB_GATHER_AUX);
+		}
 	}
 	const uint32_t oU[4] = { b0.x, b0.y, b0.z, b0.w };
+	const int nU_here = pi.nU - first; /* (wave-uniform: a scalar compare and branch per group of eight U rows) */
 #pragma unroll
 	for (int r = 0; r < NU / 8; r++) {
 		const uint32_t slice = (r & 1) ? sl1 : sl0;
-		if (oU[r] != NONE32) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
+		if (nU_here > 8 * r) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(buckets + (size_t)(oU[r] + slice)), (void __attribute__((address_space(3))) *)(uintptr_t)(sbase + 8192u + 1024u * r), 16, 0, BWB_GATHER_AUX);
 	}
 	/* (Tried, session 12: the loads as structured-buffer loads - record = slice, idle owners out of range, no exec mask, three instructions
 	 * a load instead of nine.  Correct on every test index and wrong at GRCh37 size: without swizzling the range check works on bytes,
@@ -401,10 +407,13 @@ template <typename P> struct ListW {
  * of four branches this was until round 4 cost more scalar mask bookkeeping per trip (25 instructions) than it did work. */
 template <typename P> __device__ __forceinline__ void list_add(ListW<P> &l, Intv<P> *base, int sel, P L, P U, int cap) {
 	const bool has = l.T != 0;
-	const bool merge = has && L == (P)(l.tU + 1);
-	const bool flush = has && !merge;
-	if (flush) { Intv<P> *buf = base + sel * cap; buf[l.T - 1].L = l.tL; buf[l.T - 1].U = l.tU; }
-	const bool first = flush && l.T == 1;
+	const bool merge = has & (L == (P)(l.tU + 1));
+	const bool flush = has & !merge;
+	/* The tail goes to its slot WHATEVER happens to it (round 5): when it is merged, or when there is none yet (slot 0), the slot is written
+	 * again before anything reads it - a list's readers take the intervals below the tail from memory and the tail from registers - and
+	 * all but one append in two hundred flush anyway: the branch around the store was a divergent region per trip, 2.6 trips per iteration. */
+	{ Intv<P> *buf = base + sel * cap; const int at = l.T > 0 ? l.T - 1 : 0; Intv<P> v; v.L = l.tL; v.U = l.tU; buf[at] = v; }
+	const bool first = flush & (l.T == 1);
 	l.fL = first ? l.tL : l.fL; l.fU = first ? l.tU : l.fU;
 	l.tL = merge ? l.tL : L;
 	l.tU = U;
@@ -804,6 +813,9 @@ template <typename P, bool WIDE> struct LHeap {
 			for (int j = d >= 64 ? 0 : 64 - d; j < 64 && s + j < nbk; j++) if (j == 0 || bstate[s + j] != NONE32) neW |= 1ull << j;
 		}
 		side_load();
+		/* (the states just loaded are waited for HERE, inside the branch: left pending, they make the compiler put an `s_waitcnt vmcnt(0)`
+		 * where the branches meet again - in front of every pop of the wave, which then sits out the previous iteration's stores) */
+		asm volatile("" :: "v"(cst), "v"(stX), "v"(stGo), "v"(stGe));
 		top_valid = false; sec_valid = false; cprev = 0;
 	}
 	/* Chunk sources, in order: chunks this read has already emptied (fhead); the lane's private run of `keep` consecutive
@@ -1180,6 +1192,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	} else {
 		for (int k = 0; k < nb; k++) h.bstate[k] = NONE32;
 	}
+	__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): nothing is pending when the loop is entered (what a resume loads is in its registers) - see the end of the loop */
 
 	for (;;) {
 		STAMP(7);
@@ -1352,9 +1365,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			alpha = MULTI && from_pop && (is_group || (rd_max_diff - (int)((e.f >> 8) & 255u) - (int)((e.f >> 16) & 255u) - (int)(e.f >> 24)) != 0);
 			iL = e.L; iU = e.U;                        /* (the popped entry's interval - and, in an exact tail, the tail of the current list: cL / cU) */
 		}
-		if (ex && s != curT - 1) {
-			if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* fetched at the end of the previous step */
-			else { /* (only the iteration after a resume: waited for inside the branch, see LHeap::pop) */
+		{
+			const bool mid = ex & (s != curT - 1), take = mid & nxi_valid;
+			iL = take ? nxi.L : iL; iU = take ? nxi.U : iU; /* fetched at the end of the previous step */
+			if (mid & !nxi_valid) { /* (only the iteration after a resume: waited for inside the branch, see LHeap::pop) */
 				const Intv<P> v = (lbase + (cursel ? lcap : 0))[s]; iL = v.L; iU = v.U;
 				asm volatile("" :: "v"(iL), "v"(iU));
 			}
@@ -1405,7 +1419,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		if (nreq > 0) ne = wave_children<P>(buckets, last_row, need_rank, iL, iU, alpha, sb, stage, zero_row, lane, n_bkt, kc); /* every lane of the wave loads */
 		__builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): what was issued ahead of the gather (prefetch128 / prefetch32: the record, LHeap::prefetch) has landed, also when no lane needed a rank */
 		h.give_back(pf_free);
-		if (want_rec) {
+		{ /* (unconditional: a lane that wants no record reads none of the three - and a region around eleven instructions costs four) */
 			/* bytes j, j + 1 of a record's six D bytes are D[i-2], D[i-1] for i = 4 m + j; wd / ws hold them as {D[i-1] low, D[i-2] high} */
 			/* (one v_perm_b32 per pair: byte j + 1 of the eight bytes {rec.y : rec.x} into byte 0, byte j into byte 1, zeros above) */
 			const uint32_t jb = (uint32_t)widx & 3u;
@@ -1457,9 +1471,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		const int diff_left = rd_max_diff - e_mm - e_go - e_ge;
 		const int diff_left_seed = kq.max_diff_seed - e_mm - e_go - e_ge;
 		const int seed_index = e_i - (rd_len - kq.seed_length);
-		const bool pruned = diff_left < 0                                                          /* :313 */
-		                    || (e_i > 0 && diff_left < (int)(wd & 127u))                            /* :317 */
-		                    || (seed_index > 0 && diff_left_seed < (int)(ws & 127u));               /* :326 */
+		/* (`|` and `&` on purpose, here and below: with `||` / `&&` the compiler builds a divergent region per short circuit - mask, branch,
+		 * restore - around three or four instructions that every wave executes anyway: tools/bbprof.py counted 82 such regions per iteration) */
+		const bool pruned = (diff_left < 0)                                                        /* :313 */
+		                    | ((e_i > 0) & (diff_left < (int)(wd & 127u)))                          /* :317 */
+		                    | ((seed_index > 0) & (diff_left_seed < (int)(ws & 127u)));             /* :326 */
 		const bool live = from_pop && !is_group && !pruned;
 		const bool do_hit = live && e_i == 0, do_tail = live && e_i != 0 && diff_left == 0, do_expand = live && e_i != 0 && diff_left != 0;
 #ifdef BWB_HIST
@@ -1487,27 +1503,20 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			STAMP(8);
 			/* ---- expansion :377-504 ---- */
 			r_vis_a += (uint32_t)kc.nvis;
-			bool allow_diff = true, allow_indels = true, allow_mm = true, allow_open = true, allow_extend = true;
-			if (e_i - 1 > 0) {
-				const int d1 = wd & 255u, d2 = (wd >> 8) & 255u;
-				if ((diff_left - 1) < (d2 & 127)) allow_diff = false;
-				else if ((d1 & 127) == diff_left - 1 && (d2 & 127) == diff_left - 1 && (d1 & 128)) allow_mm = false;
-			}
-			if (seed_index - 1 > 0) {
-				const int d1 = ws & 255u, d2 = (ws >> 8) & 255u;
-				if ((diff_left_seed - 1) < (d2 & 127)) allow_diff = false;
-				else if ((d1 & 127) == diff_left_seed - 1 && (d2 & 127) == diff_left_seed - 1 && (d1 & 128)) allow_mm = false;
-			}
+			/* :386-432, as expressions (a mismatch that the bound forbids does not matter once no difference is allowed at all) */
+			const int d1 = wd & 255u, d2 = (wd >> 8) & 255u, d1s = ws & 255u, d2s = (ws >> 8) & 255u;
+			const bool cD = e_i - 1 > 0, cS = seed_index - 1 > 0;
+			const bool allow_diff = !((cD & ((diff_left - 1) < (d2 & 127))) | (cS & ((diff_left_seed - 1) < (d2s & 127))));
+			const bool allow_mm = !((cD & ((d1 & 127) == diff_left - 1) & ((d2 & 127) == diff_left - 1) & ((d1 & 128) != 0))
+			                        | (cS & ((d1s & 127) == diff_left_seed - 1) & ((d2s & 127) == diff_left_seed - 1) & ((d1s & 128) != 0)));
 			const int tmp = e_go + e_ge;
-			if ((e_i - 1 < kq.no_indel_length + tmp) || ((rd_len - (e_i - 1)) < kq.no_indel_length + tmp)) allow_indels = false;
-			if (e_go >= kq.max_gapo && e_ge >= kq.max_gape) allow_indels = false;
-			if (e_go >= kq.max_gapo) allow_open = false;
-			if (e_ge >= kq.max_gape) allow_extend = false;
+			const bool allow_open = e_go < kq.max_gapo, allow_extend = e_ge < kq.max_gape;
+			const bool allow_indels = !((e_i - 1 < kq.no_indel_length + tmp) | ((rd_len - (e_i - 1)) < kq.no_indel_length + tmp)) & (allow_open | allow_extend);
 			const bool gap_open = e_state == STATE_M;
 			const int sc0 = e_score;
-			const bool ins_ok = allow_diff && allow_indels && ((e_state == STATE_I && allow_extend) || (e_state == STATE_M && allow_open));
-			const bool del_ok = allow_diff && allow_indels && e_state != STATE_I && (e_state == STATE_M ? allow_open : allow_extend);
-			const bool mm_ok = allow_diff && allow_mm;
+			const bool ins_ok = allow_diff & allow_indels & (((e_state == STATE_I) & allow_extend) | ((e_state == STATE_M) & allow_open));
+			const bool del_ok = allow_diff & allow_indels & (e_state != STATE_I) & (e_state == STATE_M ? allow_open : allow_extend);
+			const bool mm_ok = allow_diff & allow_mm;
 			const uint32_t mem = cr > 3 ? 0u : (MULTI ? member_mask(cr) : 2u << cr);
 			/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
 			const uint32_t delm = del_ok ? ne : 0u;
@@ -1760,8 +1769,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 
 		STAMP(15);
 		HIST(H_TOP_RELOAD, ld_cnt != 0);
-		/* (a top that is still missing: something else than a match went on top of the cached bucket - equal or zero penalties only) */
-		if (active && !exact_mode && !h.top_valid && h.cst != NONE32) { h.load_top(h.cst); ld_cnt++; }
+		/* (A top that is still missing - something else than a match went on top of the cached bucket, equal or zero penalties only - is
+		 * fetched by the next pop, which waits for it inside its branch.  Rounds 3-5 issued that load here, to have it under way: an ordinary
+		 * load that the compiler sees pending on the loop's back edge, so it put an `s_waitcnt vmcnt(0)` in front of the pop of EVERY
+		 * iteration - a wait for the iteration's stores, a memory round trip that a wave with its SIMD to itself sits out in full, for a
+		 * load that one iteration in a hundred issues: tools/bbprof.py listing, session 9.) */
 		/* heap entries stored / fetched: two per-lane accumulators, summed over the wave ONCE per launch (after the loop: one LDS atomic whose
 		 * index goes through a vector register the compiler knows nothing about - with an address it can prove wave-uniform it replaces the
 		 * atomic by a 64-trip scalar loop).  Round 4 did that atomic in every iteration: 64 lanes on one LDS address were the bank conflicts

@@ -15,8 +15,6 @@ cd $R
 if [ $PRC -ne 0 ]; then tail -40 $O/pytest.log; echo "GPU tests failed: no evidence is taken on kernels that are not green"; exit 1; fi
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
 cd /tmp && export TMPDIR=/tmp
-# (one more A/B line for profiles/r5_ab_steps.txt: session 7's product against HEAD)
-bash $R/tools/ab_bench.sh r5final_ab "--steps 6 --warmup 2 --no-extras" s7:bwbble_amd/tools_exp/libbwbble_hip_s7.so product > $O/ab.txt 2>&1; cat $O/ab.txt
 bash $R/tools/pmc_traffic.sh r5_c3 > $O/pmc_c3.log 2>&1; tail -3 $O/pmc_c3.log; cp $R/gpurun_out/r5_c3_pmc.json $R/profiles/r5_c3_pmc.json 2>/dev/null   # (so that the bench line below can quote it)
 ( export BWB_BENCH_BUDGET_S=5000; time timeout 3000 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_args.log 2> $O/bench_driver_args.err
 grep '^{"metric"' $O/bench_driver_args.log > $O/r5_bench_line_driver_args.json; tail -3 $O/bench_driver_args.err | cut -c1-200
