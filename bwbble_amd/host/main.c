@@ -160,7 +160,8 @@ int main(int argc, char *argv[]) {
 		fq_close(fs);
 		clock_gettime(CLOCK_MONOTONIC, &t1);
 		double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-		printf("{\"parse_reads\": %llu, \"parse_s\": %.4f, \"parse_reads_per_s\": %.0f, \"checksum\": %llu", (unsigned long long)n, dt, n / (dt > 0 ? dt : 1), (unsigned long long)cks);
+		extern double fq_prof_s[3];
+		printf("{\"parse_reads\": %llu, \"parse_s\": %.4f, \"parse_reads_per_s\": %.0f, \"parse_stages_s\": {\"scan\": %.3f, \"alloc\": %.3f, \"encode\": %.3f}, \"checksum\": %llu", (unsigned long long)n, dt, n / (dt > 0 ? dt : 1), fq_prof_s[0], fq_prof_s[1], fq_prof_s[2], (unsigned long long)cks);
 		if (argc >= 4) {
 			alns_batch_t *b = alnsf2alns_bin(argv[3]);
 			double best = 1e30; size_t bytes = 0;

@@ -7,7 +7,12 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <time.h>
 #include "bwb_host.h"
+
+/* stage clocks of the streaming reader (hostbench prints them): record scan, output allocation, base encoding */
+double fq_prof_s[3];
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 static inline uint8_t nt4(char c) { /* nt4_table io.h:113-130: A0 G1 C2 T3, everything else 4 */
 	switch (c) {
@@ -262,7 +267,9 @@ static int fq_scan_region(fq_stream *s) {
 
 int fq_next_chunk(fq_stream *s, uint32_t max_reads, fq_chunk_t *out) {
 	memset(out, 0, sizeof(*out));
+	double t0 = now_s();
 	while (s->n_rec - s->next_rec < max_reads && fq_scan_region(s)) { }
+	fq_prof_s[0] += now_s() - t0; t0 = now_s();
 	size_t avail = s->n_rec - s->next_rec;
 	if (avail == 0) return 0;
 	const uint32_t n = avail < max_reads ? (uint32_t)avail : max_reads;
@@ -274,6 +281,7 @@ int fq_next_chunk(fq_stream *s, uint32_t max_reads, fq_chunk_t *out) {
 	uint8_t *seq = (uint8_t *)malloc((size_t)n * stride);
 	const char *raw = s->raw;
 	const size_t *soff = s->soff + s->next_rec;
+	fq_prof_s[1] += now_s() - t0; t0 = now_s();
 #pragma omp parallel for schedule(static)
 	for (long i = 0; i < (long)n; i++) {
 		uint8_t *d = seq + (size_t)i * stride;
@@ -282,6 +290,7 @@ int fq_next_chunk(fq_stream *s, uint32_t max_reads, fq_chunk_t *out) {
 		for (; k < len[i]; k++) d[k] = nt4(q[k]);   /* io.c:467 */
 		for (; k < (int)stride; k++) d[k] = 4;
 	}
+	fq_prof_s[2] += now_s() - t0;
 	s->next_rec += n;
 	out->n = n; out->stride = stride; out->max_len = max_len; out->seq = seq; out->len = len;
 	s->count += n;
