@@ -83,7 +83,7 @@ static inline unsigned char *aln_rec_put(const bwb_aln *a, unsigned char *o) {
 }
 unsigned char *alns2alnf_buf(const bwb_aln *alns, const uint64_t *aln_off, uint32_t n_reads, size_t *len) {
 	size_t *pos = (size_t *)malloc(((size_t)n_reads + 1) * sizeof(size_t));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(bwb_host_team())
 	for (long r = 0; r < (long)n_reads; r++) {
 		size_t b = 4;
 		for (uint64_t i = aln_off[r]; i < aln_off[r + 1]; i++) {
@@ -96,7 +96,7 @@ unsigned char *alns2alnf_buf(const bwb_aln *alns, const uint64_t *aln_off, uint3
 	pos[0] = 0;
 	for (uint32_t r = 0; r < n_reads; r++) pos[r + 1] += pos[r];
 	unsigned char *buf = (unsigned char *)malloc(pos[n_reads] ? pos[n_reads] : 1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(bwb_host_team())
 	for (long r = 0; r < (long)n_reads; r++) {
 		unsigned char *o = buf + pos[r];
 		const int32_t ne = (int32_t)(aln_off[r + 1] - aln_off[r]);

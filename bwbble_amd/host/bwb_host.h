@@ -12,6 +12,8 @@
 #ifndef BWB_HOST_H
 #define BWB_HOST_H
 #include <stdint.h>
+#include <stdlib.h>
+#include <unistd.h>
 #include <stdio.h>
 #include "bwbble_hip.h"
 
@@ -111,5 +113,19 @@ int check_precalc_file(const char *preFname); /* the walk of load_precalc_sa_int
 
 /* sam.c */
 void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFname, int is_multiref, int max_diff, int n_gpus); /* align.c:494-556 */
+
+
+/* The OpenMP teams of the host stages of `align` / `aln2sam` (base encoding, .aln serialisation, SAM text) have at most 32 threads unless
+ * OMP_NUM_THREADS says otherwise: on the GPU box (2 x 64 cores, 256 hardware threads) a team of 256 - every hardware thread spinning in
+ * libgomp's barriers next to its sibling - parsed 8.8 M reads/s and serialised 8.5 M records/s where 32 threads do 33 M and 240 M
+ * (tools/r5_hostbox.sh, profiles/r5_host_stage_threads.txt), and `align -g 8` runs one serialising team per GPU worker.  A clause on
+ * every region, not omp_set_num_threads(): the regions run in pthreads, which do not inherit the caller's setting.  `index` keeps the
+ * default team. */
+static inline int bwb_host_team(void) {
+	const char *e = getenv("OMP_NUM_THREADS");
+	if (e && atoi(e) > 0) return atoi(e);
+	const long nc = sysconf(_SC_NPROCESSORS_ONLN);
+	return nc < 1 ? 1 : (nc < 32 ? (int)nc : 32);
+}
 
 #endif

@@ -92,7 +92,7 @@ reads_t *fastq2reads(const char *readsFname) {
 	R->stride = R->max_len ? R->max_len : 1;
 	R->seq = (uint8_t *)malloc((n ? n : 1) * (size_t)R->stride);
 	memset(R->seq, 4, (n ? n : 1) * (size_t)R->stride);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(bwb_host_team())
 	for (long i = 0; i < (long)n; i++) {
 		uint8_t *d = R->seq + (size_t)i * R->stride;
 		const char *s = raw + soff[i];
@@ -282,7 +282,7 @@ int fq_next_chunk(fq_stream *s, uint32_t max_reads, fq_chunk_t *out) {
 	const char *raw = s->raw;
 	const size_t *soff = s->soff + s->next_rec;
 	fq_prof_s[1] += now_s() - t0; t0 = now_s();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(bwb_host_team())
 	for (long i = 0; i < (long)n; i++) {
 		uint8_t *d = seq + (size_t)i * stride;
 		const char *q = raw + soff[i];

@@ -96,7 +96,7 @@ void alns2sam(char *fastaFname, char *readsFname, char *alnsFname, char *samFnam
 	size_t *lens = (size_t *)calloc(WAVE, sizeof(size_t));
 	for (size_t b0 = 0; b0 < nblk; b0 += WAVE) {
 		const size_t nb_ = nblk - b0 < WAVE ? nblk - b0 : WAVE;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(bwb_host_team())
 		for (long bi = 0; bi < (long)nb_; bi++) {
 			const size_t r0 = (b0 + (size_t)bi) * BLK, r1 = r0 + BLK < n ? r0 + BLK : n;
 			size_t cap = 0;
