@@ -4,10 +4,10 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r5index; mkdir -p $O
 W=/tmp/ib; mkdir -p $W; cd $W
 B=$R/bwbble_amd/bin
-$B/bwb_synth genome g.fa 400000000 4 160000 21 > /dev/null
+$B/bwb_synth genome g.fa 400000000 4 160000 21 > /dev/null; ls -la g.fa
 for t in 256 128 64 32; do
   rm -f g.fa.bwt g.fa.ann g.fa.ref
-  /usr/bin/time -f "OMP_NUM_THREADS=$t  wall %e s  user %U s  sys %S s  maxrss %M KB" env OMP_NUM_THREADS=$t $B/bwbble index g.fa > /dev/null
+  echo -n "OMP_NUM_THREADS=$t  "; TIMEFORMAT="wall %R s  user %U s  sys %S s"; time OMP_NUM_THREADS=$t $B/bwbble index g.fa > /dev/null
   md5sum g.fa.bwt | cut -c1-12
 done 2>&1 | tee $O/sweep.txt
-rm -f g.fa.bwt; /usr/bin/time -f "GOMP_SPINCOUNT=0 (256)  wall %e s  user %U s  sys %S s" env GOMP_SPINCOUNT=0 $B/bwbble index g.fa > /dev/null 2>> $O/sweep.txt; tail -1 $O/sweep.txt
+rm -f g.fa.bwt; ( echo -n "GOMP_SPINCOUNT=0 (256)  "; TIMEFORMAT="wall %R s  user %U s  sys %S s"; time GOMP_SPINCOUNT=0 $B/bwbble index g.fa > /dev/null ) 2>&1 | tee -a $O/sweep.txt
