@@ -402,7 +402,7 @@ def cli_end_to_end(a, fa, fq, flags, value, ctx, bw):
         hb = subprocess.run([bw.HOST_BIN, "hostbench", fq, kept], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
         hj = json.loads(hb.stdout.strip().splitlines()[-1])
         res["host_pipeline"] = {"parse_reads_per_s": hj["parse_reads_per_s"], "write_records_per_s": hj.get("write_records_per_s"), "reads": hj["parse_reads"],
-                                "cores": os.cpu_count(), "what": "FASTQ record scan (parallel, verified against the sequential scan) + base encoding; .aln record serialisation of the run above"}
+                                "parse_stages_s": hj.get("parse_stages_s"), "cores": os.cpu_count(), "openmp_team": "at most 32 threads per region (bwb_host.h)", "what": "FASTQ record scan (parallel, verified against the sequential scan) + base encoding; .aln record serialisation of the run above"}
     except Exception as e:  # noqa: BLE001
         res["host_pipeline"] = {"error": str(e)[-200:]}
     # f1: `bwbble aln2sam` on the same records - SA(L) of every mapped read by the invPsi walk on the GPU (k_locate: up to 31

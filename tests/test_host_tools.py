@@ -473,3 +473,23 @@ def test_chunk_serialiser_writes_the_record_writers_bytes(built, golden, tmp_pat
     run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(one)])
     run([bw.HOST_BIN, "alncat", os.path.join(golden, aln), str(buf), "buf", chunk])
     assert open(buf, "rb").read() == open(one, "rb").read()
+
+@pytest.mark.parametrize("team", ["1", "3", "64"])
+def test_host_stages_do_not_depend_on_the_openmp_team(built, golden, tmp_path, monkeypatch, team):
+    """host/bwb_host.h bwb_host_team(): the teams of the host stages are a clause on every region (at most 32 threads unless
+    OMP_NUM_THREADS says otherwise - a team of 256 hardware threads was 4-30 x slower on the GPU box, profiles/r5_host_stage_threads.txt).
+    Whatever the team, the reader's chunks and the serialiser's bytes are the same; `hostbench` reports both rates and the reader's stages."""
+    import json
+    monkeypatch.setenv("OMP_NUM_THREADS", team)
+    fq, aln = os.path.join(golden, "sim_chr21_N100.fastq"), os.path.join(golden, "sim_chr21_N100_n2.aln")
+    whole, parts, one, buf = tmp_path / "whole.tsv", tmp_path / "parts.txt", tmp_path / "one.aln", tmp_path / "buf.aln"
+    run([bw.HOST_BIN, "dumpreads", fq, str(whole)])
+    run([bw.HOST_BIN, "dumpreads", fq, str(parts), "17"])
+    assert open(parts).read().split("\n")[:-1] == [ln.split("\t")[1] for ln in open(whole).read().split("\n")[:-1]]
+    run([bw.HOST_BIN, "alncat", aln, str(one)])
+    run([bw.HOST_BIN, "alncat", aln, str(buf), "buf", "13"])
+    assert open(buf, "rb").read() == open(one, "rb").read()
+    r = subprocess.run([bw.HOST_BIN, "hostbench", fq, aln], stdout=subprocess.PIPE, text=True, check=True)
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["parse_reads"] == 100 and j["write_records"] == 100 and j["parse_reads_per_s"] > 0 and j["write_records_per_s"] > 0
+    assert set(j["parse_stages_s"]) == {"scan", "alloc", "encode"}
