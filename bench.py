@@ -587,7 +587,8 @@ def cpu_baseline(a, fa, fq, flags, off, alns, bw):
         except OSError:
             nodes = None
         res["numa_nodes"] = nodes
-        res.update({"value": final["reads_per_s"], "kind": "reference", "threads": best_t, "reads_per_s_per_thread": final["reads_per_s_per_thread"],
+        res.update({"cores": best_t, "host_hardware_threads": cores,  # (`cores` = the threads the quoted run used, as the bench contract asks)
+                    "value": final["reads_per_s"], "kind": "reference", "threads": best_t, "reads_per_s_per_thread": final["reads_per_s_per_thread"],
                     "reads_per_s_per_core": round(final["reads_per_s"] / min(best_t, phys), 2), "sweep": sweep, "final": final,
                     "sample": f"first {sample} reads of the same FASTQ ({final['reads_per_thread']} per thread), oracle/_ref/bwbble align -t {best_t} "
                               f"(best of the -t sweep {ts}); wall {final['wall_s']}s minus {final['load_s']}s load at the same -t"})
