@@ -11,6 +11,9 @@ hipcc's own pipeline (assembler, lld, bundler, host compile) on the patched asse
     BWB_LIB=.../libbwbble_hip_bbprof.so BWB_BBPROF_OUT=counts.json python3 bench.py ...     (GPU: the library dumps the counters with
                                                                                              every get_stats; the last line counts)
     tools/bbprof.py report counts.json [map.json]  -> dynamic instructions per wave iteration by class, by source line region, hottest blocks
+    tools/bbprof.py listing counts.json <instrumented.s> <kernel-substring> [min executions per iteration]
+                                                   -> the kernel's assembly, block by block, each block headed by its executions per wave
+                                                      iteration (what sessions 9-10 of round 5 worked from; tools/bbprof_by_source.py sums it by source region)
 
 The instrumented kernels need more registers (two waves per SIMD instead of three) and are several times slower: the COUNTS per read are
 the product's (same code, same control flow), the timings are not.  A block whose start has M0 or SCC live (the increment clobbers both)
