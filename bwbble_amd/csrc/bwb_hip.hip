@@ -942,7 +942,7 @@ static int read_device_stats(bwb_hip_ctx *c) {
 		static const char *hn[H_N] = { "iter", "pop", "pop_from_mirror", "pop_gapped", "pruned", "hit", "exact_start", "expand", "exact_step", "need_rank", "same_bkt", "two_bkt",
 			"w1", "w2", "w3_4", "w5_8", "w9_32", "w33_128", "w_big", "ne0", "ne1", "ne2", "ne3_4", "ne5_8", "ne9+", "push_gap", "push_mis", "push_match",
 			"del_ok", "mm_ok", "ins_ok", "top_reload", "wave_iters", "wave_gaploop_trips", "wave_misloop_trips", "wave_matchloop_trips", "wave_any_two_bkt", "wave_any_wide8",
-			"wave_nreq_le16", "alpha", "exact_multi", "finish", "group_pops", "wave_any_exact", "wave_any_expand", "wave_all_exact", "exp_same_w1", "exp_same_w2_4" };
+			"wave_nreq_le16", "alpha", "exact_multi", "finish", "group_pops", "wave_any_exact", "wave_any_expand", "wave_all_exact", "exp_same_w1", "exp_same_w2_4", "count_only_gap", "count_only_mis", "count_only_pop", "expand_after_hit" };
 		fprintf(stderr, "[bwb hist]");
 		for (int k = 0; k < H_N; k++) fprintf(stderr, " %s=%llu", hn[k], st[STAT_HIST + k]);
 		fprintf(stderr, "\n");

@@ -1012,7 +1012,7 @@ __device__ __forceinline__ uint32_t wave_sum5(uint32_t v) {
 enum { H_ITER = 0, H_POP, H_POP_FROM_MIRROR, H_POP_GAPPED, H_PRUNED, H_HIT, H_EXACT_START, H_EXPAND, H_EXACT_STEP, H_NEED_RANK, H_SAME_BKT, H_TWO_BKT,
        H_W1, H_W2, H_W4, H_W8, H_W32, H_W128, H_WBIG, H_NE0, H_NE1, H_NE2, H_NE3_4, H_NE5_8, H_NE9, H_PUSH_GAP, H_PUSH_MIS, H_PUSH_MATCH,
        H_DEL_OK, H_MM_OK, H_INS_OK, H_TOP_RELOAD, H_WAVE_ITERS, H_WAVE_GAPLOOP, H_WAVE_MISLOOP, H_WAVE_MATCHLOOP, H_WAVE_ANY_TWO_BKT, H_WAVE_ANY_WIDE8,
-       H_WAVE_NREQ_LE16, H_ALPHA, H_EXACT_MULTI, H_FINISH, H_ALLOC, H_WAVE_ANY_EXACT, H_WAVE_ANY_EXPAND, H_WAVE_ALL_EXACT, H_EXP_SAME_W1, H_EXP_SAME_W2_4, H_N };
+       H_WAVE_NREQ_LE16, H_ALPHA, H_EXACT_MULTI, H_FINISH, H_ALLOC, H_WAVE_ANY_EXACT, H_WAVE_ANY_EXPAND, H_WAVE_ALL_EXACT, H_EXP_SAME_W1, H_EXP_SAME_W2_4, H_PH_GAP, H_PH_MIS, H_PH_POP, H_EXPAND_AFTER_HIT, H_N };
 
 /* Slices.  One launch of kl_search = one slice of the stream of batches.  Per-read work is heavy-tailed, so a
  * launch that runs until its last read is done ends with ever fewer busy lanes.  Instead, when the cursor of the batch runs
@@ -1110,6 +1110,11 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	h.pXv = h.pX; h.pGov = h.pGo; h.pGev = h.pGe; h.nbkv = nb;
 	if (!WIDE) asm volatile("" : "+v"(h.pXv), "+v"(h.pGov), "+v"(h.pGev), "+v"(h.nbkv)); /* (the 32-byte-entry kernels have no registers to spare: there these stay scalars) */
 	h.far = WIDE && (kq.mm_score > 63 || kq.gapo_score > 63 || kq.gape_score > 63);
+#ifdef BWB_NO_PHANTOM /* (A/B: the round-5 behaviour - every pushed entry is stored) */
+	const bool ph_ok = false;
+#else
+	const bool ph_ok = nb <= 256 && !h.far; /* count-only pushes (see the expansion); wave-uniform */
+#endif
 	h.fhead = NONE32;
 	h.reset();
 
@@ -1160,7 +1165,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 #endif
 #ifdef BWB_HIST
 	unsigned long long hist[H_N] = { 0 };
-	unsigned long long hl_gap = 0, hl_mis = 0, hl_match = 0; /* per-lane sums */
+	unsigned long long hl_gap = 0, hl_mis = 0, hl_match = 0, hl_phg = 0, hl_phx = 0; /* per-lane sums */
 #endif
 	if (wk.resume && (mysave[0].x & 1u)) {
 		/* ---- resume the read this lane parked at the end of the previous slice ---- */
@@ -1339,7 +1344,10 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		 * bookkeeping and the copies of every value the branches merge: rounds 3-4 had four levels here.) */
 		const bool ex = active && exact_mode;      /* exact_match_bounded exact_match.c:82-115: interval s of the current list, read char rc[r] */
 		const bool popping = active && !exact_mode;
-		const bool can_pop = popping && !(h.num_entries == 0 || h.num_entries > kq.max_entries); /* :293,299 */
+		const bool may_pop = popping && !(h.num_entries == 0 || h.num_entries > kq.max_entries); /* :293,299 */
+		/* (count-only entries, see the expansion: when nothing is STORED any more, what the reference pops here is an entry whose score is above
+		 * best_score + mm_score - it stops, :309-311 - and which this heap never held) */
+		const bool can_pop = may_pop && (!ph_ok || h.neW != 0ull);
 		if (can_pop) {
 			if (!(h.neW & 1ull)) h.switch_cache(h.best(nb)); /* (bit 0 of the window = the cached bucket: still non-empty in all but a few dozen pops per read) */
 #ifdef BWB_HIST
@@ -1355,7 +1363,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			 * the score modulo 256 - the same number unless the parameters allow scores above 255 */
 			const bool over = can_pop && (e_score & 255) > rd_best_score + h.pXv;
 			finish = popping && (!can_pop || over);
-			r_pop += (can_pop && (!grp || over)) ? 1u : 0u;
+			r_pop += ((can_pop && (!grp || over)) || (may_pop && !can_pop)) ? 1u : 0u;
+			HIST(H_PH_POP, may_pop && !can_pop);
 			from_pop = can_pop && !over;
 			is_group = grp && !over;                   /* the children are those of the parent's O_alphabet call (:382-383) */
 			h.num_entries += is_group ? 1 : 0;
@@ -1521,16 +1530,30 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			/* push sequence (:434-504): insertion, deletions j = 1..15, then match/mismatch j = 1..15 */
 			const uint32_t delm = del_ok ? ne : 0u;
 			const uint32_t mgrp = mm_ok ? ne : (ne & mem);
-			const uint32_t matchm = mgrp & mem, mism = mgrp & ~mem;
-			const int nDel = __popc(delm), nIns = ins_ok ? 1 : 0, nX = __popc(mism), n0 = __popc(matchm);
-			const int nGc = nIns + nDel;            /* gap entries the reference pushes: what is counted */
+			const uint32_t matchm = mgrp & mem, mism_c = mgrp & ~mem;
+			const int nDel_c = __popc(delm), nIns_c = ins_ok ? 1 : 0, nX_c = __popc(mism_c), n0 = __popc(matchm);
+			const int nGc = nIns_c + nDel_c;        /* gap entries the reference pushes: what is counted */
+			const int nPush = nGc + nX_c + n0;
+			r_push += nPush;
+			/* COUNT-ONLY PUSHES (round 6).  Once the read has its first hit best_score is fixed (:333-337,349-353: set only while the read has no
+			 * alignment); entries are popped in non-decreasing score order (:594-610) and the loop stops at the first popped entry whose score is
+			 * above best_score + mm_score (:309-311) - exactly as it stops on an empty heap (:293).  A child pushed with such a score can therefore
+			 * influence the result only through heap->num_entries (:299-301): it is counted (num_entries, pushes) and NOT stored - no slot, no chunk,
+			 * no bucket mark.  Before the first hit best_score is the number of buckets and no child qualifies.  With the default penalties that is
+			 * every gap child and, for a parent above best_score, every mismatch child pushed after the first hit: more than half of all entries
+			 * the round-5 kernel stored, and nearly all that stayed in the pool until the end of the read.  (ph_ok: the scores compared are the true
+			 * ones only while they fit the reference's 8-bit field, align.h:104; and the window must see every stored bucket.) */
+			const bool ph_g = ph_ok & (scG > rd_best_score + h.pXv), ph_x = ph_ok & (e_score > rd_best_score);
+			const int nDel = ph_g ? 0 : nDel_c, nIns = ph_g ? 0 : nIns_c;
+			const uint32_t mism = ph_x ? 0u : mism_c;
+			const int nX = ph_x ? 0 : nX_c;
 			const int nG = nIns + (nDel ? 1 : 0);   /* gap entries stored: the deletions as one group (STATE_GROUP) */
-			r_push += nGc + nX + n0;
 #ifdef BWB_HIST
 			{ const int nne = __popc(ne);
 			  HIST(H_NE0, nne == 0); HIST(H_NE1, nne == 1); HIST(H_NE2, nne == 2); HIST(H_NE3_4, nne == 3 || nne == 4); HIST(H_NE5_8, nne >= 5 && nne <= 8); HIST(H_NE9, nne >= 9);
 			  HIST(H_DEL_OK, del_ok); HIST(H_MM_OK, mm_ok); HIST(H_INS_OK, ins_ok);
-			  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nGc; hl_mis += nX; hl_match += n0; }
+			  hw_g = nG; hw_x = nX; hw_0 = n0; hl_gap += nGc; hl_mis += nX_c; hl_match += n0;
+			  hl_phg += ph_g ? nGc : 0; hl_phx += ph_x ? nX_c : 0; HIST(H_EXPAND_AFTER_HIT, n_alns != 0); }
 #endif
 			/* target buckets: 0 = sc0 (the cached one), 1 = scX, 2 = scG; equal scores share a bucket in sequence order */
 			const int tX = kq.mm_score == 0 ? 0 : 1, tG = wG == 0 ? 0 : (wG == 1 ? 1 : 2);
@@ -1639,7 +1662,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 						top_ok = true;
 					}
 				} else { /* mm_score == 0: one bucket, interleaved in code order */
-					uint32_t am = mgrp;
+					uint32_t am = matchm | mism;
 					while (am) {
 						const int j = __ffs((int)am) - 1;
 						am &= am - 1;
@@ -1649,7 +1672,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					}
 				}
 				STAMP(13);
-				h.num_entries += nGc + nX + n0;
+				h.num_entries += nPush;
 				if (k0 > 0) { h.cst = st0 + (uint32_t)k0; h.mark(sc0); h.top_valid = top_ok; if (!top_ok) h.sec_valid = false; if (st0 != cst_old) h.cprev = cst_old; }
 				if (k1 > 0) { h.stX = st1 + (uint32_t)k1; h.mark(scX); }
 				if (k2 > 0) { const uint32_t v = st2 + (uint32_t)k2; if (wG == 2) h.stGo = v; else h.stGe = v; h.mark(scG); }
@@ -1834,6 +1857,8 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 	if (hl_gap) atomicAdd(&R_stats[STAT_HIST + H_PUSH_GAP], hl_gap);
 	if (hl_mis) atomicAdd(&R_stats[STAT_HIST + H_PUSH_MIS], hl_mis);
 	if (hl_match) atomicAdd(&R_stats[STAT_HIST + H_PUSH_MATCH], hl_match);
+	if (hl_phg) atomicAdd(&R_stats[STAT_HIST + H_PH_GAP], hl_phg);
+	if (hl_phx) atomicAdd(&R_stats[STAT_HIST + H_PH_MIS], hl_phx);
 #endif
 	if (!parked) mysave[0].x = 0u;
 	/* the last wave of the block to leave hands the block's recycle stack to the next slice */
