@@ -1155,7 +1155,7 @@ extern "C" int bwb_hip_set_sa(bwb_hip_ctx *c, const uint64_t *SA, uint64_t num_s
 extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, uint64_t *out_pos) {
 	if (!c || (n && (!rows || !out_pos))) return fail(BWB_E_ARG, "locate: null argument");
 	if (!c->d_SA.p) return fail(BWB_E_STATE, "locate: sampled SA not uploaded (bwb_hip_set_sa)");
-	if (n == 0) return BWB_OK;
+	if (n == 0) { c->locate_ms = 0; c->locate_steps = 0; c->locate_rows = 0; return BWB_OK; } /* (locate_stats reports THIS call) */
 	for (size_t i = 0; i < n; i++) if (rows[i] >= c->ix.length) return fail(BWB_E_ARG, "locate: row out of range");
 	HIPCHK(hipSetDevice(c->device));
 	DevMem dr, dout;
@@ -1164,6 +1164,10 @@ extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, ui
 	HIPCHK(hipMemcpyAsync(dr.p, rows, n * 8, hipMemcpyHostToDevice, c->stream));
 	const unsigned grid = (unsigned)std::min<size_t>((n + BWB_OCTS_PER_BLOCK - 1) / BWB_OCTS_PER_BLOCK, (size_t)c->num_cu * 8);
 	hipEvent_t e0 = get_event(c), e1 = get_event(c);
+	struct EvGuard { /* the two events go back to the context's free list on every way out (an error path used to leak them) */
+		bwb_hip_ctx *c; hipEvent_t a, b;
+		~EvGuard() { if (a) c->free_events.push_back(a); if (b) c->free_events.push_back(b); }
+	} evg{ c, e0, e1 };
 	if (!e0 || !e1) return fail(BWB_E_HIP, "hipEventCreate failed");
 	unsigned long long *steps = c->d_stats.as<unsigned long long>() + STAT_LOCATE_STEPS;
 	HIPCHK(hipMemsetAsync(steps, 0, 8, c->stream));
@@ -1177,7 +1181,6 @@ extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, ui
 	HIPCHK(hipStreamSynchronize(c->stream));
 	float ms = 0;
 	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-	c->free_events.push_back(e0); c->free_events.push_back(e1);
 	c->locate_ms = ms; c->locate_steps = hsteps; c->locate_rows = n;
 	return BWB_OK;
 }

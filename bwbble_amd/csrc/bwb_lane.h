@@ -731,7 +731,7 @@ template <typename P, bool WIDE> struct LHeap {
 	Lds<unsigned int> nfree;     /* chunks on that stack */
 	uint64_t neW;          /* non-empty buckets, as a window above the cached one: bit k = bucket cb + k.  Entries are popped in
 	                          non-decreasing score order and a child's score exceeds its parent's by at most one penalty, so every
-	                          non-empty bucket lies in [cb, cb + 63] (penalties above 63 are refused, bwb_hip.hip check_params) */
+	                          non-empty bucket lies in [cb, cb + 63] - with penalties up to 63; above that see `far` below */
 	int cb;                /* bucket whose state is cached in registers = score of the entry last popped */
 	uint32_t cst;
 	/* The buckets an expansion of an entry of bucket cb pushes to besides cb itself are cb + mm_score (mismatches), cb + gapo_score

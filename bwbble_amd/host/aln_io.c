@@ -125,6 +125,9 @@ alns_batch_t *alnsf2alns_bin(const char *alnFname) {
 			int32_t score, v[4], pairs;
 			if (fread(&score, 4, 1, f) < 1 || fread(&a->L, 8, 1, f) < 1 || fread(&a->U, 8, 1, f) < 1 || fread(v, 4, 4, f) < 4 || fread(&pairs, 4, 1, f) < 1)
 				bwb_die("alnsf2alns: Could not read ALN file: %s!", alnFname);
+			/* (aln_length comes from the file: the record builders index a 272-byte path with it - aln_rec_put / aln_rec_bytes -, and the
+			 * reference's own field is 8 bits wide, align.h:103: anything beyond 255, a negative count of entries or of pairs is a broken file) */
+			if (v[3] < 0 || v[3] > 255 || pairs < 0 || pairs > 256) bwb_die("alnsf2alns: %s: a record with aln_length %d and %d state pairs is not an ALN record", alnFname, v[3], pairs);
 			a->score = (uint16_t)score; a->num_mm = (uint8_t)v[0]; a->num_gapo = (uint8_t)v[1]; a->num_gape = (uint8_t)v[2];
 			a->aln_length = (uint16_t)v[3]; a->reserved = 0;
 			for (int k = 0; k < BWB_MAX_GAP_RUNS; k++) a->gap_run[k] = 0xFFFF;

@@ -96,13 +96,20 @@ bwt_t *load_bwt_start(const char *bwtFname, int loadSA) {
 	if (pread(fd, hdr, sizeof(hdr), 0) != (ssize_t)sizeof(hdr)) bwb_die("load_bwt: Could not read BWT from file: %s!", bwtFname);
 	B->length = hdr[0]; B->num_words = hdr[1]; B->num_sa = hdr[2]; B->num_occ = hdr[3]; B->sa0_index = hdr[4];
 	memcpy(B->C, hdr + 5, sizeof(bwtint_t) * (ALPHABET_SIZE + 1));
-	B->bwt = (uint32_t *)malloc((B->num_words ? B->num_words : 1) * sizeof(uint32_t));
-	B->O = (bwtint_t *)malloc((B->num_occ ? B->num_occ : 1) * ALPHABET_SIZE * sizeof(bwtint_t));
-	/* the header must be consistent BEFORE a loader thread computes a read size from it (bwt.c:161-218 writes exactly these; a crafted
-	 * num_words < 16 * (num_occ - 1) would make a unit's word count underflow) */
+	/* the header must be consistent BEFORE anything is sized from it - the allocations below, and the read sizes a loader thread computes
+	 * (bwt.c:161-218 writes exactly these; a crafted num_words < 16 * (num_occ - 1) would make a unit's word count underflow) - and the
+	 * file must hold what it promises (the reference's fread checks the same, bwt.c:104-118): a crafted header cannot ask for more memory
+	 * than the file has bytes */
 	if (B->length < 2 || B->num_occ != (B->length + 127) / 128 || B->num_words != (B->length + 7) / 8 || B->num_sa != (B->length + 31) / 32 || B->sa0_index >= B->length)
 		bwb_die("load_bwt: %s: inconsistent header (length %llu, num_words %llu, num_sa %llu, num_occ %llu)", bwtFname, (unsigned long long)B->length,
 		        (unsigned long long)B->num_words, (unsigned long long)B->num_sa, (unsigned long long)B->num_occ);
+	{
+		struct stat st;
+		const uint64_t need = sizeof(hdr) + B->num_words * sizeof(uint32_t) + B->num_occ * ALPHABET_SIZE * sizeof(bwtint_t) + (loadSA ? B->num_sa * sizeof(bwtint_t) : 0);
+		if (fstat(fd, &st) || (uint64_t)st.st_size < need) bwb_die("load_bwt: Could not read BWT from file: %s!", bwtFname);
+	}
+	B->bwt = (uint32_t *)malloc((B->num_words ? B->num_words : 1) * sizeof(uint32_t));
+	B->O = (bwtint_t *)malloc((B->num_occ ? B->num_occ : 1) * ALPHABET_SIZE * sizeof(bwtint_t));
 	if (!B->bwt || !B->O) bwb_die("load_bwt: Could not allocate memory for the BWT index. ");
 	if (loadSA) {
 		B->SA = (bwtint_t *)malloc((B->num_sa ? B->num_sa : 1) * sizeof(bwtint_t));
@@ -111,10 +118,6 @@ bwt_t *load_bwt_start(const char *bwtFname, int loadSA) {
 	bwt_loader_t *L = (bwt_loader_t *)calloc(1, sizeof(bwt_loader_t));
 	L->B = B; L->fd = fd; L->fname = strdup(bwtFname); L->load_sa = loadSA;
 	L->off_bwt = sizeof(hdr); L->off_O = L->off_bwt + B->num_words * sizeof(uint32_t); L->off_SA = L->off_O + B->num_occ * ALPHABET_SIZE * sizeof(bwtint_t);
-	{ /* the file must hold what the header promises (the reference's fread checks the same, bwt.c:104-118) */
-		struct stat st;
-		if (fstat(fd, &st) || (uint64_t)st.st_size < L->off_SA + (loadSA ? B->num_sa * sizeof(bwtint_t) : 0)) bwb_die("load_bwt: Could not read BWT from file: %s!", bwtFname);
-	}
 	L->unit = load_unit();
 	L->n_units = (B->num_occ + L->unit - 1) / L->unit;
 	L->done = (unsigned char *)calloc(L->n_units ? L->n_units : 1, 1);

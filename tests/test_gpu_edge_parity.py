@@ -97,6 +97,8 @@ def test_scratch_overflow_classes_are_exact(mid, oracle, monkeypatch):
     seqs, lens = synth_reads(fa, str(d / "o.fq"), 5000, 100, 8, sub=2.5)
     st = check(ctx, oracle, idx, ["-n", "3"], seqs, lens)
     assert st.n_overflow_reads > 0
+    # penalties above 63 (32-byte entries, LHeap::far: buckets beyond the 64-bucket window) through the same re-run classes
+    st = check(ctx, oracle, idx, ["-n", "3", "-M", "80", "-O", "90", "-E", "70"], seqs[:3000], lens[:3000])
     ctx.close()
 
 
@@ -122,6 +124,8 @@ def test_parked_and_resumed_reads_are_exact(mid, oracle, monkeypatch, env):
     # entry scores above 255 (the 8-bit wrap of aln_entry_t.score at inexact_match.c:309; 16-bit scores in the hit records)
     check(ctx, oracle, idx, ["-n", "3", "-M", "40", "-O", "45", "-E", "10"], seqs[:1500], lens[:1500])
     check(ctx, oracle, idx, ["-n", "5", "-M", "52", "-O", "60", "-E", "30"], seqs[:600], lens[:600])
+    # penalties above 63: LHeap::far's window top-up, side_flush and the save / restore of neW, cb, cst across slices
+    check(ctx, oracle, idx, ["-n", "3", "-M", "80", "-O", "90", "-E", "70"], seqs[:1500], lens[:1500])
     ctx.close()
 
 

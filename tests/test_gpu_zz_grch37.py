@@ -136,3 +136,74 @@ def test_c5_reads_match_the_reference_at_grch37_size(grch37, oracle, tmp_path):
     want, _, who = reference_bytes(fa, fq, flags, str(tmp_path), oracle)
     assert bw.aln_bytes(off, alns) == want, f"differs from {who}"
     ctx.close()
+
+
+C5_FLAGS = ["-n", "5", "-o", "1", "-e", "6", "-l", "32", "-k", "2"]
+
+
+def stream_chunks(ctx, p, seqs, lens, chunk):
+    """every chunk through the context's slots in order (slots are reused, slices park reads); returns the per-chunk results"""
+    nchunks = len(lens) // chunk
+    results = {}
+    for c in range(nchunks):
+        slot = c % bw.MAX_SLOTS
+        if c >= bw.MAX_SLOTS:
+            results[c - bw.MAX_SLOTS] = ctx.slot_result(slot)
+        ctx.slot_upload(slot, p, seqs[c * chunk:(c + 1) * chunk], lens[c * chunk:(c + 1) * chunk])
+        ctx.slot_submit(slot)
+    for c in range(max(0, nchunks - bw.MAX_SLOTS), nchunks):
+        results[c] = ctx.slot_result(c % bw.MAX_SLOTS)
+    ctx.flush()
+    return results
+
+
+def test_c5_stream_and_rerun_paths_match_the_reference_at_grch37_size(grch37, oracle, tmp_path, monkeypatch):
+    """Config C5 as a STREAM at GRCh37 size: 400 000 reads of 150 bp through the eight slots in chunks of 40 000
+    (slots reused, reads parked and resumed with 64-bit positions in their entries); the last 5 000 records must be the reference's
+    bytes.  Then the pool-exhaustion path at this size: a context with a 1 GB chunk pool gives reads up and re-runs them in the larger
+    scratch classes - same bytes - with 16-byte entries (-o 1) and with 32-byte entries (-o 2)."""
+    fa = grch37
+    n_stream, chunk, n_tail = 400_000, 40_000, 5_000
+    fq = str(tmp_path / "c5s.fq")
+    subprocess.run([bw.SYNTH_BIN, "reads", fa, fq, str(n_stream), "150", "6161", "1.0", "0.2", "0.0"], check=True)
+    seqs, lens = bw.load_fastq_codes(fq)
+    tail_fq = str(tmp_path / "c5tail.fq")
+    with open(fq) as f, open(tail_fq, "w") as g:
+        lines = f.readlines()
+        g.writelines(lines[-4 * n_tail:])
+    del lines
+    p = bw.params(C5_FLAGS)
+    ctx = bw.Context(bw.BwtFile(fa + ".bwt"))
+    t0 = time.time()
+    results = stream_chunks(ctx, p, seqs, lens, chunk)
+    st = ctx.stats()
+    assert st.n_parked_reads > 0 and st.launches_search >= n_stream // chunk
+    off, alns = results[n_stream // chunk - 1]
+    first = chunk - n_tail
+    streamed = bw.aln_bytes(off[first:] - off[first], alns[int(off[first]):int(off[-1])])
+    print(f"[grch37] C5: streamed {n_stream} reads in {time.time() - t0:.1f} s, {st.n_parked_reads} reads parked, {st.n_overflow_reads} re-run")
+    want, _, who = reference_bytes(fa, tail_fq, C5_FLAGS, str(tmp_path), oracle)
+    assert streamed == want, f"the C5 stream's last {n_tail} records differ from {who}"
+    ctx.close()
+    # the re-run path at this size: a pool that cannot hold the heaps of the reads in flight
+    monkeypatch.setenv("BWB_POOL_GB", "1")
+    ctx = bw.Context(bw.BwtFile(fa + ".bwt"))
+    off1, alns1 = ctx.align(p, seqs[-n_tail:], lens[-n_tail:])
+    st1 = ctx.stats()
+    print(f"[grch37] C5 with a 1 GB pool: {st1.n_overflow_reads} of {n_tail} reads re-run")
+    assert st1.n_overflow_reads > 0
+    assert bw.aln_bytes(off1, alns1) == want, f"re-run reads (16-byte entries) differ from {who}"
+    # 32-byte entries (-o 2), streamed in four chunks with the small pool, against the reference on the same 2 000 reads
+    n2 = 2_000
+    flags2 = ["-n", "5", "-o", "2", "-e", "6", "-l", "32", "-k", "2"]
+    fq2 = str(tmp_path / "c5o2.fq")
+    with open(tail_fq) as f, open(fq2, "w") as g:
+        g.writelines(f.readlines()[-4 * n2:])
+    ctx.reset_stats()
+    res2 = stream_chunks(ctx, bw.params(flags2), seqs[-n2:], lens[-n2:], n2 // 4)
+    st2 = ctx.stats()
+    got2 = b"".join(bw.aln_bytes(res2[c][0], res2[c][1]) for c in range(4))
+    want2, _, who2 = reference_bytes(fa, fq2, flags2, str(tmp_path), oracle)
+    print(f"[grch37] C5 -o 2 with a 1 GB pool: {st2.n_overflow_reads} of {n2} reads re-run")
+    assert got2 == want2, f"-o 2 (32-byte entries) differs from {who2}"
+    ctx.close()

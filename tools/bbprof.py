@@ -300,6 +300,15 @@ def instrument(asm_path, kernels):
 def build(flags, kernels):
     d = tempfile.mkdtemp(prefix="bbprof_")
     asm, steps = compile_steps(flags, d)
+    # The in-place prefetches of kl_search / kl_calc_d rely on a property of the GENERATED code (tools/check_prefetch_regs.py); this build does
+    # not go through the Makefile's build_checked rule, so the proof runs here, on the assembly BEFORE it is instrumented (the counters added
+    # below live in VGPRs above the kernel's own and never touch a prefetched register).  A build that fails it is not written.
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import check_prefetch_regs as cpr
+    res, _ = cpr.check_asm(asm)
+    bad = ["%s: %s" % (k, "; ".join(errs) if errs else "no prefetch site found") for k, (n, errs) in res.items() if errs or n == 0]
+    if bad or not res:
+        raise SystemExit("bbprof: this build fails the in-flight prefetch register proof, no library written:\n  " + "\n  ".join(bad or ["no kernel found"]))
     m = instrument(asm, kernels)
     for s in steps:
         subprocess.run(s, cwd=d, shell=True, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
