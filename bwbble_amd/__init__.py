@@ -21,6 +21,7 @@ EXPORTS = [
     "bwb_hip_align_batch", "bwb_hip_batch_upload", "bwb_hip_batch_run", "bwb_hip_batch_result", "bwb_hip_get_stats",
     "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate", "bwb_hip_locate_stats",
     "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush", "bwb_hip_abi_version", "bwb_hip_ctx_create_streamed", "bwb_hip_device_numa_node",
+    "bwb_hip_ctx_create_async", "bwb_hip_ctx_index_wait", "bwb_hip_setup_times",
 ]
 ABI_VERSION = 3  # BWB_HIP_ABI_VERSION (include/bwbble_hip.h)
 MAX_SLOTS = 8  # BWB_MAX_SLOTS

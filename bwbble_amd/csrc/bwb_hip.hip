@@ -26,6 +26,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/bwbble_hip.h"
 #include "bwb_kernels.h"
@@ -146,7 +147,13 @@ struct bwb_hip_ctx {
 	bool dbg = false, dbg_iters = false;
 	bwb_stats stats{};
 	double t_run0 = 0;
+	/* bwb_hip_ctx_create_async: the index upload runs on this thread; everything that launches a kernel joins it first (index_ready) */
+	std::thread idx_thread;
+	int idx_rc = BWB_OK;
+	std::string idx_err;
+	double idx_seconds = 0, pool_seconds = 0; /* index upload (context creation to the last bucket in HBM); the chunk pool's hipMalloc */
 	~bwb_hip_ctx() {
+		if (idx_thread.joinable()) idx_thread.join();
 		for (auto &pt : pending) { (void)hipEventDestroy(pt.e0); (void)hipEventDestroy(pt.e1); }
 		for (auto e : free_events) (void)hipEventDestroy(e);
 		for (auto e : launch_ev) (void)hipEventDestroy(e);
@@ -206,8 +213,69 @@ extern "C" int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint6
 	return bwb_hip_ctx_create_streamed(device, hdr, C, bwt, O, nullptr, out);
 }
 
-extern "C" int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
-                                           const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out) {
+/* the upload: re-layout on the GPU, chunk by chunk behind the caller's loader (runs on the creating thread, or on the context's own
+ * thread after bwb_hip_ctx_create_async) */
+static int index_upload(bwb_hip_ctx *c, uint64_t num_words, uint64_t sa0, const uint64_t *C, const uint32_t *bwt, const uint64_t *O, const volatile uint64_t *blocks_ready) {
+	const double t0 = wall_s();
+	HIPCHK(hipSetDevice(c->device));
+	const uint64_t nblk = c->ix.nblk;
+	/* superblock base table (a superblock's row is filled in when the upload below reaches its first block: with a streamed index the
+	 * host arrays are still being read) */
+	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
+	/* 2^20 blocks (128 M characters) per chunk: reference arrays -> 128-character buckets in a staging
+	 * buffer (k_relayout) -> the index's 64-character buckets (k_relayout64); the two staging sets alternate so that the copy
+	 * of chunk k+1 overlaps the kernels of chunk k */
+	const uint64_t CH = 1ull << 20;
+	DevMem d_bwt[2], d_O[2], d_b128[2], d_sbc;
+	Event ev_k[2];
+	for (int t = 0; t < 2; t++) {
+		HIPCHK(d_bwt[t].alloc(std::min(CH, nblk) * 64));
+		HIPCHK(d_O[t].alloc(std::min(CH, nblk) * 128));
+		HIPCHK(d_b128[t].alloc(std::min(CH, nblk) * 128));
+		HIPCHK(ev_k[t].create());
+	}
+	HIPCHK(d_sbc.alloc(sbcount.size() * 8));
+	int t = 0;
+	for (uint64_t b0 = 0; b0 < nblk; b0 += CH, t ^= 1) {
+		const uint64_t nb = std::min(CH, nblk - b0);
+		const uint64_t w0 = b0 * 16, nw = std::min(nb * 16, num_words - w0);
+		wait_blocks(blocks_ready, b0 + nb); /* streamed: the loader has read this chunk of the .bwt file */
+		for (uint64_t blk = b0; blk < b0 + nb; blk += (1ull << BWB_SB_SHIFT) - (blk & ((1ull << BWB_SB_SHIFT) - 1))) {
+			if (blk & ((1ull << BWB_SB_SHIFT) - 1)) continue; /* (on to the next superblock start inside this chunk) */
+			const uint64_t sb = blk >> BWB_SB_SHIFT;
+			const uint32_t first = bwt[blk * 16] >> 28;
+			for (int j = 0; j < 16; j++) {
+				sbcount[sb * 16 + j] = O[blk * 16 + j] - ((first == (uint32_t)j && !(j == 0 && blk * 128 == sa0)) ? 1 : 0);
+				c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
+			}
+			HIPCHK(hipStreamSynchronize(c->stream)); /* (the kernels queued so far read the table: a superblock is 16 chunks, this is rare) */
+			HIPCHK(hipMemcpy(d_sbc.p, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice));
+		}
+		HIPCHK(hipEventSynchronize(ev_k[t].e)); /* the kernel that read this staging set two chunks ago */
+		HIPCHK(hipMemcpyAsync(d_bwt[t].p, bwt + w0, nw * 4, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(d_O[t].p, O + b0 * 16, nb * 128, hipMemcpyHostToDevice, c->stream));
+		const uint64_t nthreads = nb * 8;
+		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt[t].as<uint32_t>(), d_O[t].as<uint64_t>(), b0, nb, nw,
+		                   sa0, d_sbc.as<uint64_t>(), d_b128[t].as<uint4>());
+		HIPCHK(hipGetLastError());
+		hipLaunchKernelGGL(k_relayout64, dim3((unsigned)((nb * 2 + 255) / 256)), dim3(256), 0, c->stream, d_b128[t].as<uint4>(), nb, c->d_buckets.as<uint4>() + b0 * 16);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(ev_k[t].e, c->stream));
+	}
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->idx_seconds = wall_s() - t0;
+	return BWB_OK;
+}
+
+/* joins the upload thread of an asynchronously created context; its error becomes this call's */
+static int index_ready(bwb_hip_ctx *c) {
+	if (c->idx_thread.joinable()) c->idx_thread.join();
+	if (c->idx_rc) return fail(c->idx_rc, "index upload: " + c->idx_err);
+	return BWB_OK;
+}
+
+static int ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt, const uint64_t *O,
+                      const volatile uint64_t *blocks_ready, bool async, bwb_hip_ctx **out) {
 	if (!hdr || !C || !bwt || !O || !out) return fail(BWB_E_ARG, "ctx_create: null argument");
 	const uint64_t length = hdr[0], num_words = hdr[1], num_occ = hdr[3];
 	const uint64_t nblk = (length + 127) / 128;
@@ -232,10 +300,6 @@ extern "C" int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], co
 	c->dbg_iters = getenv("BWB_DEBUG_ITERS") != nullptr;
 	if (getenv("BWB_SLICE_ITERS")) c->slice_iters = (uint32_t)strtoul(getenv("BWB_SLICE_ITERS"), nullptr, 10);
 	c->force_slices = getenv("BWB_FORCE_SLICES") != nullptr || c->slice_iters != 0;
-
-	/* superblock base table (a superblock's row is filled in when the upload below reaches its first block: with a streamed index the
-	 * host arrays are still being read) */
-	std::vector<uint64_t> sbcount(BWB_NSB_MAX * 16, 0);
 	memset(&c->ix, 0, sizeof(c->ix));
 	for (uint64_t sb = 0; sb < BWB_NSB_MAX; sb++)
 		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j];
@@ -245,55 +309,51 @@ extern "C" int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], co
 	c->ix.nblk = nblk;
 	c->sa0_index = hdr[4];
 	c->pos32 = length < 0xFFFFFFFFull && !getenv("BWB_FORCE_POS64");
-
-	/* re-layout on the GPU, 2^20 blocks (128 M characters) per chunk: reference arrays -> 128-character buckets in a staging
-	 * buffer (k_relayout) -> the index's 64-character buckets (k_relayout64); the two staging sets alternate so that the copy
-	 * of chunk k+1 overlaps the kernels of chunk k */
-	const uint64_t CH = 1ull << 20;
-	DevMem d_bwt[2], d_O[2], d_b128[2], d_sbc;
-	Event ev_k[2];
-	for (int t = 0; t < 2; t++) {
-		HIPCHK(d_bwt[t].alloc(std::min(CH, nblk) * 64));
-		HIPCHK(d_O[t].alloc(std::min(CH, nblk) * 128));
-		HIPCHK(d_b128[t].alloc(std::min(CH, nblk) * 128));
-		HIPCHK(ev_k[t].create());
+	if (!async) {
+		int rc = index_upload(c.get(), num_words, hdr[4], C, bwt, O, blocks_ready);
+		if (rc) return rc;
+	} else {
+		bwb_hip_ctx *cp = c.get();
+		const uint64_t sa0 = hdr[4];
+		cp->idx_thread = std::thread([cp, num_words, sa0, C, bwt, O, blocks_ready]() {
+			cp->idx_rc = index_upload(cp, num_words, sa0, C, bwt, O, blocks_ready);
+			if (cp->idx_rc) cp->idx_err = g_err; /* (g_err is per thread: handed to whoever joins) */
+		});
 	}
-	HIPCHK(d_sbc.alloc(sbcount.size() * 8));
-	int t = 0;
-	for (uint64_t b0 = 0; b0 < nblk; b0 += CH, t ^= 1) {
-		const uint64_t nb = std::min(CH, nblk - b0);
-		const uint64_t w0 = b0 * 16, nw = std::min(nb * 16, num_words - w0);
-		wait_blocks(blocks_ready, b0 + nb); /* streamed: the loader has read this chunk of the .bwt file */
-		for (uint64_t blk = b0; blk < b0 + nb; blk += (1ull << BWB_SB_SHIFT) - (blk & ((1ull << BWB_SB_SHIFT) - 1))) {
-			if (blk & ((1ull << BWB_SB_SHIFT) - 1)) continue; /* (on to the next superblock start inside this chunk) */
-			const uint64_t sb = blk >> BWB_SB_SHIFT;
-			const uint32_t first = bwt[blk * 16] >> 28;
-			for (int j = 0; j < 16; j++) {
-				sbcount[sb * 16 + j] = O[blk * 16 + j] - ((first == (uint32_t)j && !(j == 0 && blk * 128 == hdr[4])) ? 1 : 0);
-				c->ix.base[sb][j] = C[j] + sbcount[sb * 16 + j];
-			}
-			HIPCHK(hipStreamSynchronize(c->stream)); /* (the kernels queued so far read the table: a superblock is 16 chunks, this is rare) */
-			HIPCHK(hipMemcpy(d_sbc.p, sbcount.data(), sbcount.size() * 8, hipMemcpyHostToDevice));
-		}
-		HIPCHK(hipEventSynchronize(ev_k[t].e)); /* the kernel that read this staging set two chunks ago */
-		HIPCHK(hipMemcpyAsync(d_bwt[t].p, bwt + w0, nw * 4, hipMemcpyHostToDevice, c->stream));
-		HIPCHK(hipMemcpyAsync(d_O[t].p, O + b0 * 16, nb * 128, hipMemcpyHostToDevice, c->stream));
-		const uint64_t nthreads = nb * 8;
-		hipLaunchKernelGGL(k_relayout, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, c->stream, d_bwt[t].as<uint32_t>(), d_O[t].as<uint64_t>(), b0, nb, nw,
-		                   hdr[4], d_sbc.as<uint64_t>(), d_b128[t].as<uint4>());
-		HIPCHK(hipGetLastError());
-		hipLaunchKernelGGL(k_relayout64, dim3((unsigned)((nb * 2 + 255) / 256)), dim3(256), 0, c->stream, d_b128[t].as<uint4>(), nb, c->d_buckets.as<uint4>() + b0 * 16);
-		HIPCHK(hipGetLastError());
-		HIPCHK(hipEventRecord(ev_k[t].e, c->stream));
-	}
-	HIPCHK(hipStreamSynchronize(c->stream));
 	*out = c.release();
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                                           const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out) {
+	return ctx_create(device, hdr, C, bwt, O, blocks_ready, false, out);
+}
+
+extern "C" int bwb_hip_ctx_create_async(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                                        const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out) {
+	return ctx_create(device, hdr, C, bwt, O, blocks_ready, true, out);
+}
+
+extern "C" int bwb_hip_ctx_index_wait(bwb_hip_ctx *c, double *seconds) {
+	if (!c) return fail(BWB_E_ARG, "ctx_index_wait: null context");
+	int rc = index_ready(c);
+	if (rc) return rc;
+	if (seconds) *seconds = c->idx_seconds;
+	return BWB_OK;
+}
+
+extern "C" int bwb_hip_setup_times(bwb_hip_ctx *c, double *index_seconds, double *pool_seconds, uint64_t *pool_bytes) {
+	if (!c) return fail(BWB_E_ARG, "setup_times: null context");
+	if (index_seconds) *index_seconds = c->idx_thread.joinable() ? -1.0 : c->idx_seconds; /* (-1: the upload is still running) */
+	if (pool_seconds) *pool_seconds = c->pool_seconds;
+	if (pool_bytes) *pool_bytes = c->d_pool.bytes;
 	return BWB_OK;
 }
 
 extern "C" void bwb_hip_ctx_destroy(bwb_hip_ctx *c) {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
+	if (c->idx_thread.joinable()) c->idx_thread.join(); /* (the upload thread reads the caller's arrays: they are free once this returns) */
 	(void)hipDeviceSynchronize();
 	delete c;
 }
@@ -343,7 +403,8 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	if (c->parked) return BWB_OK; /* parked reads hold chunks of the present pool: keep it (the admission control copes) */
 	c->d_pool.release();
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
-	HIPCHK(c->d_pool.alloc(want));
+	{ const double t0 = wall_s(); HIPCHK(c->d_pool.alloc(want)); c->pool_seconds += wall_s() - t0; }
+	if (c->dbg) fprintf(stderr, "[bwb] chunk pool: %.1f GB allocated in %.2f s\n", (double)want / (1u << 30), c->pool_seconds);
 	if (!c->d_pool_bump.p) HIPCHK(c->d_pool_bump.alloc(2 * POOL_REGIONS * 64));
 	return BWB_OK;
 }
@@ -697,7 +758,9 @@ static int submit(bwb_hip_ctx *c, int si, bool suspend) {
 	Slot &s = c->slots[si];
 	if (!s.uploaded) return fail(BWB_E_STATE, "slot_submit: nothing uploaded into this slot");
 	if (s.submitted && !s.complete) return fail(BWB_E_STATE, "slot_submit: the slot is still in flight");
-	int rc = ensure_class(c, 0);
+	int rc = index_ready(c); /* (a context created with bwb_hip_ctx_create_async: its index upload may still be running) */
+	if (rc) return rc;
+	rc = ensure_class(c, 0);
 	if (rc) return rc;
 	HIPCHK(hipStreamWaitEvent(c->stream, s.ev_up.e, 0));
 	HIPCHK(hipMemsetAsync(s.d_ctl.p, 0, 256, c->stream));
@@ -1044,6 +1107,8 @@ extern "C" int bwb_hip_calc_d(bwb_hip_ctx *c, int32_t *out_D, int32_t *out_Dseed
 	HIPCHK(hipSetDevice(c->device));
 	int rc = bwb_hip_flush(c);
 	if (rc) return rc;
+	rc = index_ready(c);
+	if (rc) return rc;
 	const size_t nD = (size_t)s.n_reads * (s.maxlen + 1) * 2, nS = (size_t)s.n_reads * (c->kp.seed_length + 1) * 2;
 	DevMem dD, dS;
 	HIPCHK(dD.alloc((nD ? nD : 1) * 4));
@@ -1087,6 +1152,7 @@ extern "C" int bwb_hip_rank16(bwb_hip_ctx *c, const uint64_t *pos, size_t n, int
 	for (size_t i = 0; i < n; i++)
 		if (pos[i] != ~0ull && pos[i] >= c->ix.length) return fail(BWB_E_ARG, "rank16: position out of range");
 	HIPCHK(hipSetDevice(c->device));
+	{ int rc = index_ready(c); if (rc) return rc; }
 	DevMem dp, dout;
 	HIPCHK(dp.alloc(n * 8));
 	HIPCHK(dout.alloc(n * 128));
@@ -1104,6 +1170,7 @@ static int rank_bench(bwb_hip_ctx *c, int layout, size_t n, int iters, uint64_t 
 	if (!c || n < 4 || iters < 1) return fail(BWB_E_ARG, "rank_bench: bad argument");
 	n &= ~(size_t)3;
 	HIPCHK(hipSetDevice(c->device));
+	{ int rc = index_ready(c); if (rc) return rc; }
 	unsigned long long *cs = c->d_misc.as<unsigned long long>();
 	HIPCHK(hipMemsetAsync(cs, 0, 8, c->stream));
 	const unsigned grid = (unsigned)(c->num_cu * 8);
@@ -1158,6 +1225,7 @@ extern "C" int bwb_hip_locate(bwb_hip_ctx *c, const uint64_t *rows, size_t n, ui
 	if (n == 0) { c->locate_ms = 0; c->locate_steps = 0; c->locate_rows = 0; return BWB_OK; } /* (locate_stats reports THIS call) */
 	for (size_t i = 0; i < n; i++) if (rows[i] >= c->ix.length) return fail(BWB_E_ARG, "locate: row out of range");
 	HIPCHK(hipSetDevice(c->device));
+	{ int rc = index_ready(c); if (rc) return rc; }
 	DevMem dr, dout;
 	HIPCHK(dr.alloc(n * 8));
 	HIPCHK(dout.alloc(n * 8));

@@ -60,7 +60,8 @@ typedef struct {
 	aln_params_t *params;
 	pipe_t *pp;
 	bwb_stats total;
-	double kernel_ms, t_ctx;
+	double kernel_ms, t_ctx, t_pool, t_first_submit; /* index upload; the chunk pool's hipMalloc; worker start to the first slice queued */
+	unsigned long long pool_bytes;
 	unsigned long long n_reads; /* reads of the chunks this worker took */
 } worker_t;
 
@@ -156,11 +157,12 @@ static void *gpu_worker(void *arg) {
 	pin_to_device_node(w->device, dbg);
 	double tq = wall();
 	const bwtint_t hdr[5] = { w->BWT->length, w->BWT->num_words, w->BWT->num_sa, w->BWT->num_occ, w->BWT->sa0_index };
-	/* the index goes to the GPU while the loader threads are still reading the tail of the .bwt file (bwt_io.c) */
-	if (bwb_hip_ctx_create_streamed(w->device, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, w->BWT->loader ? &w->BWT->blocks_ready : NULL, &ctx))
+	/* The index goes to the GPU - on a thread of the library - while the loader threads are still reading the tail of the .bwt file
+	 * (bwt_io.c), and while this thread already uploads its first chunk: that first slot_upload sizes and allocates the context's scratch
+	 * and its heap chunk pool (seconds of hipMalloc at GRCh37 scale, which rounds 3-5 paid AFTER the index upload); slot_submit waits for
+	 * the index by itself. */
+	if (bwb_hip_ctx_create_async(w->device, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, w->BWT->loader ? &w->BWT->blocks_ready : NULL, &ctx))
 		bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
-	w->t_ctx = wall() - tq;
-	if (dbg) { fprintf(stderr, "[bwb host] worker %d (device %d): context + index upload %.3f s\n", w->gpu, w->device, w->t_ctx); tq = wall(); }
 	enum { NS = BWB_MAX_SLOTS }; /* chunks in flight: the heaviest reads of a chunk take several slices' time (they are parked and resumed), and
 	                                a slot can be uploaded again only when its chunk is complete */
 	chunk_t *in_slot[NS];
@@ -181,9 +183,19 @@ static void *gpu_worker(void *arg) {
 		}
 		const int slot = (int)(j % NS);
 		if (j >= NS && retired + NS <= j) { retire(w, ctx, slot, in_slot[slot]); retired++; } /* the slot's previous chunk: NS - 1 slices stay queued while the host waits */
-		if (bwb_hip_slot_upload(ctx, slot, w->params, c->fq.seq, c->fq.len, c->fq.n, c->fq.stride, c->carry, c->carry_len) ||
-		    bwb_hip_slot_submit(ctx, slot))
+		if (bwb_hip_slot_upload(ctx, slot, w->params, c->fq.seq, c->fq.len, c->fq.n, c->fq.stride, c->carry, c->carry_len))
 			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+		if (j == 0) { /* the first chunk is staged, scratch and pool exist: now the index must be complete */
+			if (bwb_hip_ctx_index_wait(ctx, &w->t_ctx)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+			uint64_t pb = 0;
+			bwb_hip_setup_times(ctx, NULL, &w->t_pool, &pb);
+			w->pool_bytes = pb;
+			if (dbg) fprintf(stderr, "[bwb host] worker %d (device %d): index upload %.3f s, chunk pool %.1f GB allocated in %.3f s, first chunk staged at +%.3f s\n", w->gpu, w->device, w->t_ctx,
+			                 (double)pb / (1u << 30), w->t_pool, wall() - tq);
+		}
+		if (bwb_hip_slot_submit(ctx, slot))
+			bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+		if (j == 0) w->t_first_submit = wall() - tq;
 		free(c->fq.seq); free(c->fq.len); free(c->carry); c->fq.seq = NULL; c->fq.len = NULL; c->carry = NULL; /* (staged by the library: the caller's buffers are free) */
 		in_slot[slot] = c;
 		w->n_reads += c->fq.n;
@@ -266,13 +278,17 @@ int align_reads_inexact_gpu_stream(bwt_t *BWT, const char *readsFname, aln_param
 	}
 	pthread_join(rth, NULL);
 	bwb_stats tot; memset(&tot, 0, sizeof(tot));
-	double kms = 0, tctx = 0;
+	double kms = 0, tctx = 0, tpool = 0, tfirst = 0;
+	unsigned long long pool_bytes = 0;
 	for (int g = 0; g < n_gpus; g++) {
 		pthread_join(th[g], NULL);
 		tot.visits_single += ws[g].total.visits_single; tot.visits_alphabet += ws[g].total.visits_alphabet;
 		tot.heap_pops += ws[g].total.heap_pops; tot.n_alignments += ws[g].total.n_alignments; tot.n_overflow_reads += ws[g].total.n_overflow_reads;
 		if (ws[g].kernel_ms > kms) kms = ws[g].kernel_ms;
 		if (ws[g].t_ctx > tctx) tctx = ws[g].t_ctx;
+		if (ws[g].t_pool > tpool) tpool = ws[g].t_pool;
+		if (ws[g].t_first_submit > tfirst) tfirst = ws[g].t_first_submit;
+		if (ws[g].pool_bytes > pool_bytes) pool_bytes = ws[g].pool_bytes;
 		if (n_gpus > 1) /* one line per worker: an uneven node (a slow link, a busy socket) shows here, not in the total */
 			printf("  GPU %d (device %d, NUMA node %d): reads %llu  kernel %.1f ms  index to HBM %.2f sec  launches %llu  parked reads %llu  re-run reads %llu\n", g, ws[g].device,
 			       bwb_hip_device_numa_node(ws[g].device), (unsigned long long)ws[g].n_reads, ws[g].kernel_ms, ws[g].t_ctx,
@@ -282,6 +298,9 @@ int align_reads_inexact_gpu_stream(bwt_t *BWT, const char *readsFname, aln_param
 	printf("GPUs: %d  reads: %llu  wall: %.3f sec (%.0f reads/s incl. index upload)  kernel: %.1f ms  index to HBM: %.2f sec  first chunk parsed after: %.2f sec  rank-block visits: %llu  hits: %llu  re-run reads: %llu\n",
 	       n_gpus, (unsigned long long)pp.n_reads, dt, pp.n_reads / (dt > 0 ? dt : 1), kms, tctx, pp.t_first_chunk, (unsigned long long)(tot.visits_single + tot.visits_alphabet),
 	       (unsigned long long)tot.n_alignments, (unsigned long long)tot.n_overflow_reads);
+	/* where the start-up went (the three overlap): the .bwt file in memory | the index in HBM | the chunk pool's hipMalloc | first slice queued */
+	printf("start-up: .bwt read %.2f sec | index to HBM %.2f sec | chunk pool %.1f GB in %.2f sec | first slice queued after %.2f sec\n",
+	       bwt_load_seconds(BWT), tctx, (double)pool_bytes / (1u << 30), tpool, tfirst);
 	free(ws); free(th);
 	pthread_mutex_destroy(&pp.mu); pthread_cond_destroy(&pp.cv_work); pthread_cond_destroy(&pp.cv_done); pthread_cond_destroy(&pp.cv_space);
 	fclose(alnFile);

@@ -37,6 +37,7 @@ typedef struct {
 	/* load_bwt_start: the arrays are filled by loader threads while the GPUs already take the index in */
 	volatile uint64_t blocks_ready;   /* leading 128-character blocks whose bwt words and O rows are in memory (release/acquire) */
 	void *loader;                     /* opaque: the loader threads (NULL: everything is loaded) */
+	double load_seconds;              /* load_bwt_start to the last byte of the file in memory */
 } bwt_t;
 
 /* reads_t/read_t (io.h:151-194) in structure-of-arrays form: codes are read->seq (A0 G1 C2 T3 N4) */
@@ -70,6 +71,7 @@ void bwb_die(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)
 /* bwt_io.c */
 void store_bwt(const bwt_t *BWT, const char *bwtFname);                /* bwt.c:66-82 */
 bwt_t *load_bwt(const char *bwtFname, int loadSA);                     /* bwt.c:90-125 */
+double bwt_load_seconds(const bwt_t *B);
 bwt_t *load_bwt_start(const char *bwtFname, int loadSA);               /* returns after the header: the arrays fill in the background (blocks_ready) */
 void load_bwt_wait(bwt_t *BWT);                                        /* until the whole file is in memory */
 void free_bwt(bwt_t *BWT);

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include "bwb_host.h"
 
@@ -49,6 +50,7 @@ typedef struct {
 	pthread_mutex_t mu;
 	pthread_t th[16];
 	int n_threads;
+	double t0;
 } bwt_loader_t;
 
 static void pread_all(int fd, void *buf, size_t n, uint64_t off, const char *fname) {
@@ -71,6 +73,13 @@ static void *bwt_loader_thread(void *arg) {
 		pthread_mutex_unlock(&L->mu);
 		if (u >= L->n_units) {
 			if (do_sa) pread_all(L->fd, B->SA, B->num_sa * sizeof(bwtint_t), L->off_SA, L->fname);
+			{ /* (the last thread to get here names the moment the file was in memory) */
+				struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+				const double now = ts.tv_sec + 1e-9 * ts.tv_nsec - L->t0;
+				pthread_mutex_lock(&L->mu);
+				if (now > B->load_seconds) B->load_seconds = now;
+				pthread_mutex_unlock(&L->mu);
+			}
 			return NULL;
 		}
 		const uint64_t LOAD_UNIT = L->unit;
@@ -127,6 +136,7 @@ bwt_t *load_bwt_start(const char *bwtFname, int loadSA) {
 	if (L->n_threads < 1) L->n_threads = 1;
 	if (L->n_threads > 16) L->n_threads = 16;
 	B->loader = L;
+	{ struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); L->t0 = ts.tv_sec + 1e-9 * ts.tv_nsec; }
 	for (int t = 0; t < L->n_threads; t++)
 		if (pthread_create(&L->th[t], NULL, bwt_loader_thread, L)) bwb_die("load_bwt: cannot start a loader thread");
 	return B;
@@ -142,6 +152,8 @@ void load_bwt_wait(bwt_t *B) {
 	B->loader = NULL;
 	__atomic_store_n(&B->blocks_ready, B->num_occ, __ATOMIC_RELEASE);
 }
+
+double bwt_load_seconds(const bwt_t *B) { return B ? B->load_seconds : 0.0; } /* (complete once load_bwt_wait has returned or blocks_ready == num_occ) */
 
 bwt_t *load_bwt(const char *bwtFname, int loadSA) {
 	bwt_t *B = load_bwt_start(bwtFname, loadSA);

@@ -211,6 +211,12 @@ static int fq_scan_region(fq_stream *s) {
 	if (s->p >= sz) return 0;
 	const long p0 = s->p, e = p0 + s->region < sz ? p0 + s->region : sz;
 	const int T = s->threads;
+	{ /* a cold file: ask for this region and the next one now (asynchronous read-ahead), instead of having sixteen scanner threads fault
+	   * their parts in 128 KB at a time */
+		const long pg = sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096;
+		const long a0 = p0 / pg * pg, a1 = p0 + 2 * s->region < sz ? p0 + 2 * s->region : sz;
+		if (a1 > a0) madvise((void *)(raw + a0), (size_t)(a1 - a0), MADV_WILLNEED);
+	}
 	fq_part_t *parts = (fq_part_t *)calloc((size_t)T, sizeof(fq_part_t));
 	long *bnd = (long *)malloc(((size_t)T + 1) * sizeof(long));
 	for (int t = 0; t <= T; t++) bnd[t] = p0 + (long)(((__int128)(e - p0) * t) / T);

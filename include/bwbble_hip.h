@@ -109,6 +109,18 @@ int bwb_hip_ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], 
  * everything is there (= bwb_hip_ctx_create).  Several contexts (one per GPU) may follow the same counter. */
 int bwb_hip_ctx_create_streamed(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
                                 const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out);
+/* The same, returning as soon as the context exists: the index upload runs on a thread of the library, so the caller can already
+ * slot_upload its first batch - which also sizes and allocates the context's scratch and heap chunk pool, seconds of hipMalloc at GRCh37
+ * scale - while the index is still on its way.  The host arrays (and *blocks_ready) must stay valid until bwb_hip_ctx_index_wait has
+ * returned; every entry point that launches a kernel waits by itself (slot_submit, batch_run, calc_d, rank16, rank_bench, locate), and so
+ * does ctx_destroy.  index_wait reports an upload error (the message through bwb_hip_last_error) and, optionally, the upload's seconds.
+ * (Added in round 6 without a version change: no structure or existing entry point changed.) */
+int bwb_hip_ctx_create_async(int device, const uint64_t hdr[5], const uint64_t C[17], const uint32_t *bwt,
+                             const uint64_t *O, const volatile uint64_t *blocks_ready, bwb_hip_ctx **out);
+int bwb_hip_ctx_index_wait(bwb_hip_ctx *ctx, double *seconds);
+/* where a context's start-up time went: seconds of the index upload (-1 while it is running), seconds spent in the hipMalloc of the heap
+ * chunk pool and the pool's size (any pointer may be NULL) */
+int bwb_hip_setup_times(bwb_hip_ctx *ctx, double *index_seconds, double *pool_seconds, uint64_t *pool_bytes);
 void bwb_hip_ctx_destroy(bwb_hip_ctx *ctx);
 
 /* Replaces align_reads_inexact[_parallel] for one batch (inexact_match.c:25-168): calculate_d x2 +
