@@ -260,6 +260,7 @@ def main():
                      "device_bytes_per_launch": dom["device_bytes_per_launch"],
                      "algorithmic_bytes_per_launch": int(dom["visits_per_step"] * a.steps / max(dom["launches"], 1) * ALG_BYTES_PER_VISIT),
                      "kernel_ms_per_launch": dom["ms_per_launch"], "achieved_ref_layout_GBs": dom["ref_layout_GBs"],
+                     "s8d_check": s8d_check(dom, a),
                      "kernels": {"kl_search": k_search, "kl_calc_d": k_calcd},
                      "lanes_busy_of_64": round(st.lane_iterations / max(st.wave_iterations, 1), 1),
                      "reads_parked_per_step": int(st.n_parked_reads / a.steps),
@@ -293,6 +294,18 @@ def main():
     grp.close()
 
 
+def s8d_check(dom, a):
+    """SURVEY 8(d)'s unit (192 B per rank visit: the REFERENCE layout's checkpoint row + BWT block) against the HBM peak.  It is no upper-bound
+    check for this layout - a visit moves one 128-byte bucket, and an L-1 / U pair in one bucket is fetched once - so the priced rate may exceed
+    the peak; the line says so here instead of in a note."""
+    vis, bkt = dom["visits_per_step"], dom["bucket_bytes_per_step"] / DEV_BYTES_PER_BUCKET
+    rate = dom["ref_layout_GBs"]
+    return {"bytes": int(vis * a.steps / max(dom["launches"], 1) * ALG_BYTES_PER_VISIT), "rate_GBs": rate, "over_peak": bool(rate > HBM_PEAK_GBS),
+            "buckets_per_visit": round(bkt / vis, 3) if vis else None,
+            "why": f"{(bkt / vis if vis else 0):.2f} buckets fetched per visit x {DEV_BYTES_PER_BUCKET} B in this layout against 192 B per visit in the reference's: "
+                   "`frac` follows the device bytes, this figure prices the reference layout and is not a fraction of anything"}
+
+
 def source_hash():
     """sha256 over the kernel sources: a stored PMC profile is quoted only for the code it was measured on"""
     import hashlib
@@ -316,6 +329,17 @@ def measured_traffic(a, B, dom_name, dom):
             continue
         if pj.get("source_hash") != source_hash():
             return None, f"{os.path.relpath(prof, ROOT)} was measured on other kernel sources (hash {pj.get('source_hash')}, now {source_hash()}): not quoted"
+        pl = pj[dom_name].get("per_launch")
+        if isinstance(pl, dict) and pl["slice"]["launches"] and (pl["drain"]["launches"] or dom_name != "kl_search"):
+            # every dispatch of the profile was priced on its own (tools/pmc_traffic_summary.py): this run's traffic is a SUM - its slices at a
+            # slice's measured bytes plus its draining launches at a drain's - over its launches
+            n_drain = max(dom["launches"] - a.steps, 0) if dom_name == "kl_search" else 0
+            n_slice = dom["launches"] - n_drain
+            tot = n_slice * pl["slice"]["hbm_bytes_per_launch"] + n_drain * (pl["drain"]["hbm_bytes_per_launch"] or 0)
+            return (tot / max(dom["launches"], 1),
+                    f"{os.path.relpath(prof, ROOT)}: separate rocprofv3 --pmc passes of this command ({pj.get('steps_in_pass')} steps) on this kernel source (hash {pj['source_hash']}), "
+                    f"every dispatch priced on its own; {pj.get('method', '')}; here: ({n_slice} slices x {pl['slice']['hbm_bytes_per_launch']:.4g} B + {n_drain} draining "
+                    f"launch(es) x {(pl['drain']['hbm_bytes_per_launch'] or 0):.4g} B) / {dom['launches']} launches; NOT measured in this run (counters need the profiler attached)")
         # (the profile's own passes have fewer steps per draining launch than this run: scale its bytes per STEP to this run's launches)
         return (pj[dom_name]["hbm_bytes_per_step"] * a.steps / max(dom["launches"], 1),
                 f"{os.path.relpath(prof, ROOT)}: separate rocprofv3 --pmc passes of this command on this kernel source (hash {pj['source_hash']}); "

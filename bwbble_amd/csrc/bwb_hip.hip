@@ -108,6 +108,8 @@ struct Slot {
 	std::vector<uint64_t> h_aln_off;
 	std::vector<bwb_aln> h_alns;
 	Event ev_up;
+	bool calcd_queued = false;    /* kl_calc_d of this batch has been queued ahead of its submit, on the context's second kernel stream (calcd_ahead) */
+	Event ev_calcd;
 	uint64_t launch = 0;          /* sequence number of the slice that was fed from this slot */
 	/* control words on the device (d_ctl, 64 bytes apart): the work cursor, the number of finished reads, the hit count */
 	uint32_t *ctl_counter() const { return d_ctl.as<uint32_t>(); }
@@ -121,6 +123,8 @@ struct PendingTime { hipEvent_t e0, e1; int kind; }; /* kind 0 = kl_calc_d, 1 = 
 struct bwb_hip_ctx {
 	int device = 0, num_cu = 0;
 	hipStream_t stream = nullptr, cstream = nullptr, rstream = nullptr; /* kernels; uploads; results */
+	hipStream_t dstream = nullptr;      /* kl_calc_d of the batches AHEAD of the one being searched (calcd_ahead > 0) */
+	int calcd_ahead = 0;                /* BWB_CALCD_AHEAD: how many uploaded slots beyond the submitted one get their kl_calc_d queued on dstream at once */
 	DevIndex ix{};
 	DevMem d_buckets, d_SA, d_stats, d_descs, d_misc;
 	uint64_t sa0_index = 0, num_sa = 0;
@@ -145,6 +149,8 @@ struct bwb_hip_ctx {
 	double locate_ms = 0; uint64_t locate_steps = 0, locate_rows = 0; /* the last bwb_hip_locate call */
 	bool force_slices = false;          /* BWB_FORCE_SLICES: the one-batch API parks and resumes too (tests) */
 	bool dbg = false, dbg_iters = false;
+	const char *launch_log = nullptr;   /* BWB_LAUNCH_LOG=<file>: one JSON line per class-0 kernel launch (synchronises after every launch: a profiling aid) */
+	unsigned long long log_prev[16] = { 0 };
 	bwb_stats stats{};
 	double t_run0 = 0;
 	/* bwb_hip_ctx_create_async: the index upload runs on this thread; everything that launches a kernel joins it first (index_ready) */
@@ -160,6 +166,7 @@ struct bwb_hip_ctx {
 		if (stream) (void)hipStreamDestroy(stream);
 		if (cstream) (void)hipStreamDestroy(cstream);
 		if (rstream) (void)hipStreamDestroy(rstream);
+		if (dstream) (void)hipStreamDestroy(dstream);
 	}
 };
 
@@ -298,8 +305,17 @@ static int ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], c
 	HIPCHK(hipMemsetAsync(c->d_stats.p, 0, sizeof(unsigned long long) * STAT_WORDS, c->stream));
 	c->dbg = getenv("BWB_DEBUG") != nullptr;
 	c->dbg_iters = getenv("BWB_DEBUG_ITERS") != nullptr;
+	c->launch_log = getenv("BWB_LAUNCH_LOG");
+	if (c->launch_log && !*c->launch_log) c->launch_log = nullptr;
 	if (getenv("BWB_SLICE_ITERS")) c->slice_iters = (uint32_t)strtoul(getenv("BWB_SLICE_ITERS"), nullptr, 10);
 	c->force_slices = getenv("BWB_FORCE_SLICES") != nullptr || c->slice_iters != 0;
+	if (getenv("BWB_CALCD_AHEAD")) c->calcd_ahead = std::max(0, std::min(BWB_MAX_SLOTS - 1, atoi(getenv("BWB_CALCD_AHEAD"))));
+	if (c->calcd_ahead > 0) {
+		int lo = 0, hi = 0; /* (numerically lowest = highest priority) */
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+		const char *pe = getenv("BWB_CALCD_PRIO");
+		HIPCHK(hipStreamCreateWithPriority(&c->dstream, hipStreamNonBlocking, (pe && atoi(pe) > 0) ? hi : ((pe && atoi(pe) < 0) ? lo : 0)));
+	}
 	memset(&c->ix, 0, sizeof(c->ix));
 	for (uint64_t sb = 0; sb < BWB_NSB_MAX; sb++)
 		for (int j = 0; j < 16; j++) c->ix.base[sb][j] = C[j];
@@ -466,6 +482,7 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	const size_t bytes = b_bstate + b_lists * (k == 0 ? 2 : 1) + b_alns + b_save + b_bsave;
 	if (!(s.mem.p && s.mem.bytes >= bytes)) {
 		if (k == 0 && c->parked) return fail(BWB_E_STATE, "the class-0 scratch cannot grow while reads are parked (flush first)");
+		if (c->dstream) HIPCHK(hipStreamSynchronize(c->dstream)); /* (a kl_calc_d queued ahead works in this scratch) */
 		s.mem.release();
 		size_t fr = 0, tot = 0;
 		HIPCHK(hipMemGetInfo(&fr, &tot));
@@ -552,6 +569,8 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	Slot &s = c->slots[si];
 	if (s.submitted && !s.complete) { rc = slot_wait(c, si); if (rc) return rc; } /* the slot is being reused */
 	if (s.uploaded) HIPCHK(hipEventSynchronize(s.ev_up.e)); /* its previous H2D copy has left the pinned staging buffers */
+	if (s.calcd_queued && !s.submitted) HIPCHK(hipStreamSynchronize(c->dstream)); /* (uploaded, its kl_calc_d queued ahead, never submitted: that kernel reads the buffers) */
+	s.calcd_queued = false;
 	/* every slot in flight runs under the same parameters (they are launch arguments) */
 	if (c->have_params && memcmp(&c->p, p, sizeof(*p)) != 0 && (any_in_flight(c) || c->parked)) { rc = bwb_hip_flush(c); if (rc) return rc; }
 	/* 32-byte heap entries: more than one gap run per path - and penalties above 63, whose buckets can lie beyond the 64-bucket window of
@@ -645,40 +664,61 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	return ensure_class(c, 0);
 }
 
-static int launch_calc_d(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint32_t n_work, uint32_t *counter, int32_t *dbgD, int32_t *dbgDs) {
+/* BWB_LAUNCH_LOG: what ONE launch did - its HIP-event time and the counters it added (buckets fetched, heap entries stored / loaded, records
+ * loaded) - so that per-dispatch PMC counters (tools/pmc_traffic.sh) can be priced launch by launch, slices and the draining launch apart */
+static int log_launch(bwb_hip_ctx *c, const char *kernel, int k, int si, bool drains, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+	HIPCHK(hipStreamSynchronize(st));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	unsigned long long cur[16];
+	int rc = fetch(c, cur, c->d_stats.p, sizeof(cur));
+	if (rc) return rc;
+	if (FILE *f = fopen(c->launch_log, "a")) {
+		auto d = [&](int i) { return cur[i] - c->log_prev[i]; };
+		fprintf(f, "{\"kernel\": \"%s\", \"class\": %d, \"slot\": %d, \"drains\": %s, \"ms\": %.3f, \"buckets\": %llu, \"entries_stored\": %llu, \"entries_loaded\": %llu, \"records_loaded\": %llu}\n",
+		        kernel, k, si, drains ? "true" : "false", ms, d(kernel[3] == 'c' ? STAT_BKT_CALCD : STAT_BKT_SEARCH), d(STAT_ENT_ST), d(STAT_ENT_LD), d(STAT_REC_LD));
+		fclose(f);
+	}
+	memcpy(c->log_prev, cur, sizeof(cur));
+	return BWB_OK;
+}
+
+static int launch_calc_d(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint32_t n_work, uint32_t *counter, int32_t *dbgD, int32_t *dbgDs, hipStream_t st = nullptr) {
 	ScratchClass &sc = c->cls[k];
 	Slot &s = c->slots[si];
+	if (!st) st = c->stream;
 	Work wk{ wl, n_work, counter, (uint32_t)si, 0, 0, 0 };
-	HIPCHK(hipMemsetAsync(counter, 0, 4, c->stream));
+	HIPCHK(hipMemsetAsync(counter, 0, 4, st));
 	const uint32_t maxb = k == 0 ? (uint32_t)(c->num_cu * c->bpc_calcd) : sc.blocks;
 	const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (n_work + LANE_BLOCK - 1) / LANE_BLOCK));
 	const size_t lds = calcd_lds();
 	hipEvent_t e0 = get_event(c), e1 = get_event(c);
 	if (!e0 || !e1) return fail(BWB_E_HIP, "hipEventCreate failed");
 	c->pending.push_back(PendingTime{ e0, e1, 0 });
-	HIPCHK(hipEventRecord(e0, c->stream));
+	HIPCHK(hipEventRecord(e0, st));
 	if (c->pos32)
-		hipLaunchKernelGGL(kl_calc_d<uint32_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
+		hipLaunchKernelGGL(kl_calc_d<uint32_t>, dim3(grid), dim3(LANE_BLOCK), lds, st, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
 		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>());
 	else
-		hipLaunchKernelGGL(kl_calc_d<uint64_t>, dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
+		hipLaunchKernelGGL(kl_calc_d<uint64_t>, dim3(grid), dim3(LANE_BLOCK), lds, st, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
 		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>());
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(e1, c->stream));
+	HIPCHK(hipEventRecord(e1, st));
 	if (c->dbg) {
-		HIPCHK(hipStreamSynchronize(c->stream));
+		HIPCHK(hipStreamSynchronize(st));
 		float ms = 0;
 		HIPCHK(hipEventElapsedTime(&ms, e0, e1));
 		fprintf(stderr, "[bwb] kl_calc_d class %d slot %d: %u reads, grid %u, %.3f ms\n", k, si, n_work, grid, ms);
 	}
+	if (c->launch_log) return log_launch(c, "kl_calc_d", k, si, false, st, e0, e1);
 	return BWB_OK;
 }
 
 /* reads not longer than the seed take the D_seed bounds of the last longer read before them (k_dseed_inherit) */
-static int launch_inherit(bwb_hip_ctx *c, int si) {
+static int launch_inherit(bwb_hip_ctx *c, int si, hipStream_t st = nullptr) {
 	Slot &s = c->slots[si];
 	if (!s.inherit) return BWB_OK;
-	hipLaunchKernelGGL(k_dseed_inherit, dim3((s.n_reads + 255) / 256), dim3(256), 0, c->stream, c->h_descs[si].b, s.d_src.as<uint32_t>(), s.n_reads);
+	hipLaunchKernelGGL(k_dseed_inherit, dim3((s.n_reads + 255) / 256), dim3(256), 0, st ? st : c->stream, c->h_descs[si].b, s.d_src.as<uint32_t>(), s.n_reads);
 	HIPCHK(hipGetLastError());
 	return BWB_OK;
 }
@@ -751,6 +791,22 @@ static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 		fprintf(stderr, "[bwb] kl_search class %d slot %d: %u new reads, grid %u, %s%s, %.3f ms, pool chunks used %llu of %d x %u (fullest region asked for %u; %u private per lane)\n",
 		        k, si, n_work, grid, suspend ? "slice (parks)" : "drains", resume ? ", resumes parked reads" : "", ms, used, (int)s.sc.n_regions, s.sc.pool_cap, used_max, s.sc.keep);
 	}
+	if (c->launch_log) return log_launch(c, "kl_search", k, si, !(suspend || slice_iters != 0), c->stream, e0, e1);
+	return BWB_OK;
+}
+
+/* kl_calc_d (+ the D_seed inheritance) of an uploaded slot on the second kernel stream, ahead of the slot's submit */
+static int queue_calc_d(bwb_hip_ctx *c, int si) {
+	Slot &s = c->slots[si];
+	HIPCHK(s.ev_calcd.create());
+	HIPCHK(hipStreamWaitEvent(c->dstream, s.ev_up.e, 0));
+	HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_tot, c->dstream));
+	int rc = launch_calc_d(c, 0, si, nullptr, s.n_tot, s.ctl_counter(), nullptr, nullptr, c->dstream);
+	if (rc) return rc;
+	rc = launch_inherit(c, si, c->dstream);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(s.ev_calcd.e, c->dstream));
+	s.calcd_queued = true;
 	return BWB_OK;
 }
 
@@ -763,18 +819,33 @@ static int submit(bwb_hip_ctx *c, int si, bool suspend) {
 	rc = ensure_class(c, 0);
 	if (rc) return rc;
 	HIPCHK(hipStreamWaitEvent(c->stream, s.ev_up.e, 0));
+	const bool ahead = c->calcd_ahead > 0 && s.n_reads != 0;
+	if (ahead) { /* kl_calc_d of this batch runs (or has run) on the second kernel stream: the search waits for it (the slot's cursor is its cursor too) */
+		if (!s.calcd_queued) { rc = queue_calc_d(c, si); if (rc) return rc; }
+		HIPCHK(hipStreamWaitEvent(c->stream, s.ev_calcd.e, 0));
+	}
 	HIPCHK(hipMemsetAsync(s.d_ctl.p, 0, 256, c->stream));
 	s.submitted = true; s.complete = false; s.fetched = false; s.launch = 0;
 	if (s.n_reads == 0) { s.complete = true; s.launch = c->n_launches; return BWB_OK; }
 	HIPCHK(hipMemsetAsync(s.d_n.p, 0, (size_t)s.n_reads * 4, c->stream));
-	HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_tot, c->stream));
-	rc = launch_calc_d(c, 0, si, nullptr, s.n_tot, s.ctl_counter(), nullptr, nullptr);
-	if (rc) return rc;
-	rc = launch_inherit(c, si);
-	if (rc) return rc;
+	if (!ahead) {
+		HIPCHK(hipMemsetAsync(s.d_status.p, 0, (size_t)s.n_tot, c->stream));
+		rc = launch_calc_d(c, 0, si, nullptr, s.n_tot, s.ctl_counter(), nullptr, nullptr);
+		if (rc) return rc;
+		rc = launch_inherit(c, si);
+		if (rc) return rc;
+	}
 	rc = launch_search(c, 0, si, nullptr, s.n_reads, s.ctl_counter(), suspend);
 	if (rc) return rc;
 	s.launch = c->n_launches;
+	/* the batches the caller has uploaded beyond this one (slots are used round-robin): their kl_calc_d is queued NOW, on the second
+	 * stream, where it runs beside the search slices instead of in front of its own (the two calls are independent per read,
+	 * inexact_match.c:140-144, and kl_calc_d has its own lists) */
+	for (int k = 1; ahead && k <= c->calcd_ahead; k++) {
+		const int sj = (si + k) % BWB_MAX_SLOTS;
+		Slot &t = c->slots[sj];
+		if (t.uploaded && !t.submitted && !t.calcd_queued && t.n_reads) { rc = queue_calc_d(c, sj); if (rc) return rc; }
+	}
 	return BWB_OK;
 }
 
@@ -1043,6 +1114,7 @@ extern "C" int bwb_hip_reset_stats(bwb_hip_ctx *c) {
 	int rc = resolve_times(c, false);
 	if (rc) return rc;
 	memset(&c->stats, 0, sizeof(c->stats));
+	memset(c->log_prev, 0, sizeof(c->log_prev));
 	HIPCHK(hipMemsetAsync(c->d_stats.p, 0, sizeof(unsigned long long) * STAT_WORDS, c->stream));
 	c->t_run0 = wall_s();
 	return BWB_OK;

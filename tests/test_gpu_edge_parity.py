@@ -168,6 +168,49 @@ def test_streamed_slots_match_oracle(mid_ctx, oracle):
     check(ctx, oracle, idx, ["-n", "2"], seqs[:800], lens[:800])
 
 
+@pytest.mark.parametrize("env", [{"BWB_CALCD_AHEAD": "2"}, {"BWB_CALCD_AHEAD": "1", "BWB_SLICE_ITERS": "200"}, {"BWB_CALCD_AHEAD": "3", "BWB_CALCD_PRIO": "1", "BWB_POOL_GB": "0"}])
+def test_calc_d_queued_ahead_on_a_second_stream_is_exact(mid, oracle, monkeypatch, env):
+    """BWB_CALCD_AHEAD: kl_calc_d of the batches uploaded beyond the submitted one runs on a second kernel stream beside the search
+    slices (the search of a batch waits for its own kl_calc_d through an event).  Batches uploaded several slots ahead, slots reused,
+    short reads that inherit D_seed across batch heads, an empty batch: same bytes and work counters as the oracle."""
+    d, fa = mid
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = bw.Context(fa + ".bwt")
+    idx = oracle.load_index(fa + ".bwt")
+    seqs, lens = synth_reads(fa, str(d / "ahead.fq"), 12000, 100, 33, sub=2.0, indel=1.0, npct=1.0)
+    lens = lens.copy()
+    lens[::7] = 30  # reads not longer than the seed: their D_seed is inherited (k_dseed_inherit runs behind kl_calc_d on the second stream)
+    flags = ["-n", "3"]
+    p = bw.params(flags)
+    cuts = list(range(0, 12001, 1000))
+    cuts.insert(5, cuts[5])  # an empty batch
+    want = [oracle.align_encoded(idx, seqs[lo:hi], lens[lo:hi], oracle.params(flags))[0] for lo, hi in zip(cuts[:-1], cuts[1:])]
+    nb, nslot = len(want), bw.MAX_SLOTS
+    got = [None] * nb
+    # uploads run up to four batches ahead of the submits
+    up = sub = 0
+    def upload(j):
+        slot = j % nslot
+        if j >= nslot:
+            off, alns = ctx.slot_result(slot)
+            got[j - nslot] = bw.aln_bytes(off, alns)
+        ctx.slot_upload(slot, p, seqs[cuts[j]:cuts[j + 1]], lens[cuts[j]:cuts[j + 1]])
+    while sub < nb:
+        while up < nb and up < sub + 4:
+            upload(up); up += 1
+        ctx.slot_submit(sub % nslot); sub += 1
+    for j in range(max(0, nb - nslot), nb):
+        off, alns = ctx.slot_result(j % nslot)
+        got[j] = bw.aln_bytes(off, alns)
+    ctx.flush()
+    assert got == want
+    st = ctx.stats()
+    assert st.launches_calc_d >= nb - 1
+    check(ctx, oracle, idx, ["-n", "2"], seqs[:800], lens[:800])  # the one-batch interface on the same context
+    ctx.close()
+
+
 def test_streamed_results_are_published_before_the_host_reads_them(mid_ctx):
     """Long slices: a slot's parked reads finish INSIDE the next slot's slice, and the host fetches status, counts, offsets and
     the hit log on another stream while that kernel is still running.  The kernel publishes a read's results (release fence)

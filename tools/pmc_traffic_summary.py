@@ -15,6 +15,7 @@ import os
 import sys
 
 out_dir, dst = sys.argv[1], sys.argv[2]
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -31,6 +32,24 @@ def counters(sub):
             agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[name].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
     return agg, {k: len(v) for k, v in launches.items()}
+
+
+def per_dispatch(sub):
+    """{kernel: [counters of every dispatch, in dispatch order]}"""
+    rows = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            name = "kl_search" if "kl_search" in k else "kl_calc_d" if "kl_calc_d" in k else None
+            if name is None:
+                continue
+            rows[name][int(r.get("Dispatch_Id", 0) or 0)][r["Counter_Name"]] += float(r["Counter_Value"])
+    return {k: [v[d] for d in sorted(v)] for k, v in rows.items()}
+
+
+def launch_log(name):
+    p = os.path.join(out_dir, name)
+    return [json.loads(l) for l in open(p)] if os.path.exists(p) else []
 
 
 def source_hash():
@@ -56,9 +75,9 @@ wr, _ = counters("wr")
 line = [l for l in open(os.path.join(out_dir, "rd.json")).read().splitlines() if l.startswith('{"metric"')]
 bench = json.loads(line[-1]) if line else {}
 cfg = bench.get("config", {})
-res = {"what": "rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 0 --no-extras` (tools/pmc_traffic.sh), read-side raw counters in one pass, write side in another",
+res = {"what": f"rocprofv3 --pmc passes of `bench.py --steps {STEPS} --warmup 0 --no-extras` (tools/pmc_traffic.sh), read-side raw counters in one pass, write side in another",
        "source_hash": source_hash(), "genome_mb": cfg.get("genome_mb"), "reads": cfg.get("reads_per_gpu_per_step"),
-       "ndiff": cfg.get("max_diff"), "read_len": cfg.get("read_len"), "steps_in_pass": 2, "calibration_7GiB_table": calib,
+       "ndiff": cfg.get("max_diff"), "read_len": cfg.get("read_len"), "steps_in_pass": STEPS, "calibration_7GiB_table": calib,
        "method": "hbm read bytes = (RDREQ - RDREQ_32B) x 64 + RDREQ_32B x 32 + in-kernel bucket count x 64 (a 128-byte bucket request is one RDREQ, tallied at 64 bytes: "
                  "see calibration_7GiB_table.k_coop; a scattered 8- or 16-byte load is one 64-byte request: k_meta8/16), + WRITE_SIZE"}
 kern = bench.get("roofline", {}).get("kernels", {})
@@ -67,7 +86,7 @@ for k in ("kl_search", "kl_calc_d"):
         continue
     c, w = rd[k], wr.get(k, {})
     launches = max(nl.get(k, 1), 1)
-    steps = 2
+    steps = STEPS
     bkt_bytes = kern.get(k, {}).get("bucket_bytes_per_step", 0) * steps
     raw = (c.get("TCC_EA0_RDREQ_sum", 0) - c.get("TCC_EA0_RDREQ_32B_sum", 0)) * 64 + c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
     read = raw + bkt_bytes / 2  # the second 64 bytes of every 128-byte bucket request
@@ -79,5 +98,39 @@ for k in ("kl_search", "kl_calc_d"):
               "hbm_bytes_per_step": (read + write) / steps, "hbm_bytes_per_launch": (read + write) / launches,
               "device_bytes_per_step": dev / steps, "traffic_over_device_bytes": round((read + write) / dev, 3) if dev else None,
               "kernel_ms_per_launch_in_pass": kern.get(k, {}).get("ms_per_launch")}
+# (round 6) every dispatch priced on its own: the read pass's dispatches of a kernel, in order, are the launches of its launch log (the library
+# wrote one line per launch: buckets, entries, records, whether the launch drains); the write pass runs the same launches in the same order
+rd_d, wr_d = per_dispatch("rd"), per_dispatch("wr")
+rd_log, wr_log = launch_log("rd_launches.jsonl"), launch_log("wr_launches.jsonl")
+_fl = cfg.get("flags", "").split()
+_opt = lambda name, dflt: int(_fl[_fl.index(name) + 1]) if name in _fl else dflt
+esz = 32 if (_opt("-o", 1) > 1 or max(_opt("-M", 3), _opt("-O", 11), _opt("-E", 4)) > 63) else 16  # (bwb_hip.hip slot_upload: `wide`)
+for k in ("kl_search", "kl_calc_d"):
+    logs = [l for l in rd_log if l["kernel"] == k and l["class"] == 0]
+    rows, wrows = rd_d.get(k, []), wr_d.get(k, [])
+    if k not in res or not logs or len(logs) != len(rows) or len(wrows) != len(rows):
+        if k in res:
+            res[k]["per_launch"] = f"not available: {len(logs)} log lines, {len(rows)} read-pass dispatches, {len(wrows)} write-pass dispatches"
+        continue
+    per = []
+    for l, c, w in zip(logs, rows, wrows):
+        raw = (c.get("TCC_EA0_RDREQ_sum", 0) - c.get("TCC_EA0_RDREQ_32B_sum", 0)) * 64 + c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
+        read = raw + l["buckets"] * 64
+        write = w.get("WRITE_SIZE", 0) * 1024
+        dev = l["buckets"] * 128 + (l["entries_stored"] + l["entries_loaded"]) * esz + l["records_loaded"] * 16
+        per.append({"drains": l["drains"], "ms": l["ms"], "buckets": l["buckets"], "RDREQ": c.get("TCC_EA0_RDREQ_sum"), "WRREQ": w.get("TCC_EA0_WRREQ_sum"),
+                    "hbm_read_bytes": read, "hbm_write_bytes": write, "hbm_bytes": read + write, "device_bytes": dev})
+    sl, dr = [q for q in per if not q["drains"]], [q for q in per if q["drains"]]
+    mean = lambda v, f: sum(q[f] for q in v) / len(v) if v else None
+    res[k]["per_launch"] = {"launches": per,
+                            "slice": {"launches": len(sl), "hbm_bytes_per_launch": mean(sl, "hbm_bytes"), "device_bytes_per_launch": mean(sl, "device_bytes"), "ms_per_launch": mean(sl, "ms"),
+                                      "RDREQ_minus_buckets_per_launch": (mean(sl, "RDREQ") - mean(sl, "buckets")) if sl else None},
+                            "drain": {"launches": len(dr), "hbm_bytes_per_launch": mean(dr, "hbm_bytes"), "device_bytes_per_launch": mean(dr, "device_bytes"), "ms_per_launch": mean(dr, "ms")}}
 json.dump(res, open(dst, "w"), indent=1)
-print(json.dumps(res, indent=1)[:3000])
+print(json.dumps({k: ({kk: vv for kk, vv in v.items() if kk != 'per_launch'} if isinstance(v, dict) else v) for k, v in res.items()}, indent=1)[:3000])
+for k in ('kl_search', 'kl_calc_d'):
+    pl = res.get(k, {}).get('per_launch')
+    if isinstance(pl, dict):
+        print(k, 'slice', pl['slice'], 'drain', pl['drain'])
+    elif pl:
+        print(k, pl)
