@@ -405,8 +405,10 @@ def cli_end_to_end(a, fa, fq, flags, value, ctx, bw):
         if r.returncode != 0:
             return {"error": (r.stdout + r.stderr)[-400:]}
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("GPUs:")]
+        startup = [ln for ln in r.stdout.splitlines() if ln.startswith("start-up:")]
         res = {"value": round(n_reads / dt, 1), "unit": "reads/s", "reads": n_reads, "wall_s": round(dt, 2),
-               "command": "bwbble align " + " ".join(fl) + " <fasta> <fastq> <out.aln>", "cli_summary": line[-1] if line else ""}
+               "command": "bwbble align " + " ".join(fl) + " <fasta> <fastq> <out.aln>", "cli_summary": line[-1] if line else "",
+               "cli_startup": startup[-1] if startup else ""}
         if keep:
             os.replace(out_aln, keep)
         else:
