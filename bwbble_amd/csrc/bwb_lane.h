@@ -1453,24 +1453,42 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		bool exact_step = active && (exact_mode);
 		if (from_pop && is_group) {
 			/* ---- a deletion group has reached the top of its bucket: its children take its place ---- */
-			const int n = __popc(ne);
+			/* (a COMBINED group - the run it opens has its deletion bit clear - also holds the insertion that the reference pushed in front of the
+			 * deletions, :440-443: that entry goes in first, below the deletion children) */
+			uint64_t gr = ((uint64_t)ERUNS_HI << 32) | ERUNS_LO, gr2 = ((uint64_t)ERUNS2_HI << 32) | ERUNS2_LO;
+			const int g_run = (int)((e.f >> 16) & 255u) - 1;                 /* the run the group's gap belongs to: the children's num_gapo - 1 */
+			const int g_sh = 16 * (g_run & 3) + 15;
+			const bool g_hi = WIDE && g_run >= 4;
+#ifdef BWB_NO_GAP_COMBINE
+			const bool comb = false;
+#else
+			const bool comb = (((g_hi ? gr2 : gr) >> g_sh) & 1ull) == 0ull;
+#endif
+			const int n = __popc(ne) + (comb ? 1 : 0);
 			const uint32_t cst_old = h.cst;
 			const uint32_t st0 = h.reserve(cst_old, n, ovf, xs);
 			if (!ovf && n > 0) {
 				if (st0 != cst_old) h.cprev = cst_old; /* (a new chunk was started: its header names the state before it) */
-				const uint32_t sd = (e.sa & ~3u) | (uint32_t)STATE_D;
+				const uint32_t sd = (e.sa & 0x3FCu) | (uint32_t)STATE_D; /* (aln_length; the runs travel apart) */
 				uint32_t sx = st0, gm = ne;
+				if (comb) {
+					u32x4 w0, w1;
+					h.pack(e.L, e.U, (e.f & ~255u) | ((e.f - 1u) & 255u), (e.sa & 0x3FCu) | (uint32_t)STATE_I, (uint32_t)gr, (uint32_t)(gr >> 32), w0, w1, (uint32_t)gr2, (uint32_t)(gr2 >> 32));
+					h.store_packed(++sx, w0, w1); st_cnt++;
+					if (!WIDE) h.sw = w0;
+					if (g_hi) gr2 |= 1ull << g_sh; else gr |= 1ull << g_sh; /* the deletions' version of the run */
+				}
 				while (gm) {
 					const int j = __ffs((int)gm) - 1;
 					gm &= gm - 1;
 					P cl, cu;
 					kid(j, cl, cu);
 					u32x4 w0, w1;
-					h.pack(cl, cu, e.f, sd & 0x3FFu, ERUNS_LO, ERUNS_HI, w0, w1, ERUNS2_LO, ERUNS2_HI);
+					h.pack(cl, cu, e.f, sd, (uint32_t)gr, (uint32_t)(gr >> 32), w0, w1, (uint32_t)gr2, (uint32_t)(gr2 >> 32));
 					if (gm) { h.store_packed(++sx, w0, w1); st_cnt++; if (!WIDE) h.sw = w0; }
 					else { h.tw = w0; h.tw1 = w1; } /* (the last child is popped next: the register mirror is its only copy) */
 				}
-				h.top_valid = true; h.sec_valid = !WIDE && n >= 2; /* (n == 1 cannot happen: a single deletion child is stored as itself) */
+				h.top_valid = true; h.sec_valid = !WIDE && n >= 2; /* (n == 1 cannot happen: a single deletion child without an insertion is stored as itself) */
 				h.cst = st0 + (uint32_t)n; h.mark(e_score);
 			}
 		}
@@ -1547,7 +1565,16 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 			const int nDel = ph_g ? 0 : nDel_c, nIns = ph_g ? 0 : nIns_c;
 			const uint32_t mism = ph_x ? 0u : mism_c;
 			const int nX = ph_x ? 0 : nX_c;
+#ifdef BWB_NO_GAP_COMBINE /* (A/B: the insertion as its own entry next to the deletion group = rounds 3-5) */
 			const int nG = nIns + (nDel ? 1 : 0);   /* gap entries stored: the deletions as one group (STATE_GROUP) */
+#else
+			/* gap entries stored: ONE.  An expansion that opens gaps pushes the insertion and then the deletions onto the same bucket (:438-463;
+			 * both or neither: `ins_ok` and `del_ok` are the same condition for a STATE_M parent), and all of them derive from the parent's
+			 * interval - so the insertion rides in the deletion group (round 6: a COMBINED group, told by the clear deletion bit of the run it
+			 * opens) and is put in place, below the deletion children, when the group reaches the top of its bucket.  Gap entries were two
+			 * thirds of all entries the round-5 kernel stored at GRCh37 scale, almost none of them ever popped. */
+			const int nG = (nIns | nDel) ? 1 : 0;
+#endif
 #ifdef BWB_HIST
 			{ const int nne = __popc(ne);
 			  HIST(H_NE0, nne == 0); HIST(H_NE1, nne == 1); HIST(H_NE2, nne == 2); HIST(H_NE3_4, nne == 3 || nne == 4); HIST(H_NE5_8, nne >= 5 && nne <= 8); HIST(H_NE9, nne >= 9);
@@ -1609,10 +1636,17 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				{ /* gap pushes: insertion (keeps the interval), then the deletions of every non-empty code - as one group entry that
 				   * holds the parent's interval (a single deletion child is stored as itself) */
 					uint32_t sg = tG == 0 ? s0 : (tG == 1 ? s1 : s2);
-					if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, gruns2);
 					const uint32_t fd = f_gap | (uint32_t)(e_i & 255);
+#ifdef BWB_NO_GAP_COMBINE
+					if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, gruns2);
 					if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, gruns2_d); }
 					else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, gruns2_d);
+#else
+					if (nIns && nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_i, gruns2); /* combined: the INSERTION's runs (deletion bit clear) */
+					else if (nIns) emit(sg, e.L, e.U, f_gap | (uint32_t)((e_i - 1) & 255), (uint32_t)STATE_I | (alen1 << 2), gruns_i, gruns2);
+					else if (nDel == 1) { P cl, cu; kid(__ffs((int)delm) - 1, cl, cu); emit(sg, cl, cu, fd, (uint32_t)STATE_D | (alen1 << 2), gruns_d, gruns2_d); }
+					else if (nDel) emit(sg, e.L, e.U, fd, (uint32_t)STATE_GROUP | (alen1 << 2), gruns_d, gruns2_d);
+#endif
 					if (tG == 0) s0 = sg; else if (tG == 1) s1 = sg; else s2 = sg;
 				}
 				STAMP(12);
