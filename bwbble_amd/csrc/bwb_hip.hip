@@ -153,6 +153,13 @@ struct bwb_hip_ctx {
 	unsigned long long log_prev[16] = { 0 };
 	bwb_stats stats{};
 	double t_run0 = 0;
+	/* the calculate_d table (bwb_lane.h: DTab): entries and interval lists of all 4^K K-mers, built at the first large batch */
+	DevMem d_dtab_ent, d_dtab_pool;
+	int dtab_K = 0;                     /* 0: no table */
+	int dtab_multiref = -1;             /* the alphabet it was built for (-S has its own children) */
+	int dtab_mode = -1;                 /* BWB_DTAB: 0 never, 1 always, unset: when a batch has at least DTAB_MIN_READS reads */
+	bool dtab_failed = false;           /* a build did not fit its buffers: not tried again */
+	double dtab_seconds = 0;
 	/* bwb_hip_ctx_create_async: the index upload runs on this thread; everything that launches a kernel joins it first (index_ready) */
 	std::thread idx_thread;
 	int idx_rc = BWB_OK;
@@ -305,6 +312,7 @@ static int ctx_create(int device, const uint64_t hdr[5], const uint64_t C[17], c
 	HIPCHK(hipMemsetAsync(c->d_stats.p, 0, sizeof(unsigned long long) * STAT_WORDS, c->stream));
 	c->dbg = getenv("BWB_DEBUG") != nullptr;
 	c->dbg_iters = getenv("BWB_DEBUG_ITERS") != nullptr;
+	if (getenv("BWB_DTAB") && *getenv("BWB_DTAB")) c->dtab_mode = atoi(getenv("BWB_DTAB")) ? 1 : 0;
 	c->launch_log = getenv("BWB_LAUNCH_LOG");
 	if (c->launch_log && !*c->launch_log) c->launch_log = nullptr;
 	if (getenv("BWB_SLICE_ITERS")) c->slice_iters = (uint32_t)strtoul(getenv("BWB_SLICE_ITERS"), nullptr, 10);
@@ -403,7 +411,11 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	 * time, DESIGN.md section 2.3 - and 8 x 3 GB is little next to the pool) */
 	size_t more_slots = 0; /* slots that have no buffers yet (a caller that uploads every slot before the first submit - bench.py - has none left) */
 	for (const Slot &s : c->slots) if (s.d_reads.bytes == 0) more_slots++;
-	const size_t reserve = cls1 + cls2 + more_slots * slot_bytes + ((size_t)4 << 30);
+	/* (the calculate_d table, when it is still to be built: 4^12 entries of 32 bytes and their lists - about sixty intervals each at GRCh37
+	 * scale, never more intervals than one and a half times the BWT's rows plus one per K-mer; its BUILD borrows this pool as scratch) */
+	const size_t dtab_res = (c->dtab_mode != 0 && !c->dtab_K && !c->dtab_failed)
+	                            ? ((size_t)32 << 24) + std::min<size_t>((size_t)64 << 24, (size_t)(c->ix.length + c->ix.length / 2) + ((size_t)1 << 24)) * isz + ((size_t)1 << 28) : 0;
+	const size_t reserve = cls1 + cls2 + more_slots * slot_bytes + ((size_t)4 << 30) + dtab_res;
 	const size_t ceiling = std::min<size_t>(fr > reserve + ((size_t)1 << 30) ? fr - reserve : fr / 2, (size_t)POOL_REGIONS << 36);
 	/* Need: per read in flight, the private run (keep chunks of 1 KB, 2 KB with 32-byte entries) plus a share of the
 	 * common part that grows with the index: measured 37 KB per lane at 106 M rows, ~300 KB at 884 M, 870 KB at 6.85 G. */
@@ -664,6 +676,86 @@ extern "C" int bwb_hip_slot_upload(bwb_hip_ctx *c, int si, const bwb_params *p, 
 	return ensure_class(c, 0);
 }
 
+/* the table as the kernels see it (none: the table of another alphabet, or not built) */
+template <typename P> static DTab<P> dtab_of(const bwb_hip_ctx *c) {
+	DTab<P> t;
+	const bool use = c->dtab_K > 0 && c->dtab_multiref == (c->kp.multiref ? 1 : 0);
+	t.ent = use ? c->d_dtab_ent.as<uint4>() : nullptr;
+	t.pool = c->d_dtab_pool.as<Intv<P>>();
+	t.K = c->dtab_K;
+	return t;
+}
+
+/* Builds the calculate_d table (bwb_lane.h: DTab, k_dtab_level) for the current alphabet: K levels, each one step from the one before.  The
+ * levels' interval lists ping-pong between the two halves of the heap chunk pool, which is idle - nothing is parked, no slot in flight -
+ * when this runs (the first large batch of a context); the last level is copied into an allocation of its own size.  A build that does not
+ * fit (pool halves, memory) leaves the context without a table: kl_calc_d then computes every step, as before. */
+#define DTAB_MIN_READS 200000u
+static bool any_in_flight(const bwb_hip_ctx *c);
+template <typename P> static int build_dtab_t(bwb_hip_ctx *c, int K) {
+	const double t0 = wall_s();
+	ScratchClass &sc = c->cls[0];
+	const size_t isz = sizeof(Intv<P>);
+	const size_t half = (c->d_pool.bytes / 2) & ~(size_t)255;
+	const unsigned long long cap = half / isz;
+	DevMem entA, entB, bump;
+	const size_t nK = (size_t)1 << (2 * K);
+	HIPCHK(entA.alloc(nK * 32));
+	HIPCHK(entB.alloc(std::max<size_t>(nK / 4, 1) * 32));
+	HIPCHK(bump.alloc(8));
+	unsigned char *pool0 = c->d_pool.as<unsigned char>(), *pool1 = pool0 + half;
+	/* level 0: the empty suffix - one interval, the whole index; no restart, no visit */
+	const Intv<P> root{ (P)0, (P)(c->ix.length - 1) };
+	const uint4 e0[2] = { make_uint4(0u, (1u << 15) | (1u << 16), 0u, 0u), make_uint4(0u, 0u, 0u, 0u) };
+	/* levels alternate between the entry arrays so that level K lands in entA, and between the pool halves */
+	DevMem *ent_of[2] = { (K & 1) ? &entB : &entA, (K & 1) ? &entA : &entB }; /* ent_of[k & 1] */
+	unsigned char *pool_of[2] = { pool0, pool1 };
+	HIPCHK(hipMemcpyAsync(ent_of[0]->p, e0, sizeof(e0), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(pool_of[0], &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	const uint32_t grid = (uint32_t)(c->num_cu * c->bpc_calcd);
+	unsigned long long total = 0;
+	for (int k = 1; k <= K; k++) {
+		HIPCHK(hipMemsetAsync(bump.p, 0, 8, c->stream));
+		const uint64_t tasks = 1ull << (2 * k);
+		const uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (tasks + LANE_BLOCK - 1) / LANE_BLOCK));
+		hipLaunchKernelGGL(k_dtab_level<P>, dim3(g), dim3(LANE_BLOCK), calcd_lds(), c->stream, c->ix, c->kp.multiref, k, ent_of[(k - 1) & 1]->template as<uint4>(),
+		                   (const Intv<P> *)pool_of[(k - 1) & 1], ent_of[k & 1]->template as<uint4>(), (Intv<P> *)pool_of[k & 1], bump.as<unsigned long long>(), cap, sc.sc);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipStreamSynchronize(c->stream)); /* (the level is complete: its interval count) */
+		int rc = fetch(c, &total, bump.p, 8);
+		if (rc) return rc;
+		if (total > cap) {
+			if (c->dbg) fprintf(stderr, "[bwb] calculate_d table: level %d needs %llu intervals, the scratch holds %llu: no table\n", k, total, cap);
+			c->dtab_failed = true;
+			return BWB_OK;
+		}
+	}
+	/* the last level's lists into their own allocation (+ 64 bytes: kl_calc_d reads a list in groups of four intervals) */
+	if (c->d_dtab_pool.alloc((size_t)total * isz + 64) != hipSuccess) { (void)hipGetLastError(); c->dtab_failed = true; return BWB_OK; }
+	HIPCHK(hipMemcpyAsync(c->d_dtab_pool.p, pool_of[K & 1], (size_t)total * isz, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->d_dtab_ent.release();
+	std::swap(c->d_dtab_ent.p, entA.p); std::swap(c->d_dtab_ent.bytes, entA.bytes);
+	c->dtab_K = K; c->dtab_multiref = c->kp.multiref ? 1 : 0;
+	c->dtab_seconds = wall_s() - t0;
+	if (c->dbg) fprintf(stderr, "[bwb] calculate_d table: K = %d, %llu intervals (%.2f GB + %.2f GB of entries), built in %.3f s\n", K, total, (double)total * isz / (1u << 30),
+	                    (double)nK * 32 / (1u << 30), c->dtab_seconds);
+	return BWB_OK;
+}
+static int ensure_dtab(bwb_hip_ctx *c, uint32_t n_reads) {
+	if (c->dtab_mode == 0 || c->dtab_failed) return BWB_OK;
+	if (c->dtab_K && c->dtab_multiref == (c->kp.multiref ? 1 : 0)) return BWB_OK;
+	if (c->dtab_mode < 0 && n_reads < DTAB_MIN_READS) return BWB_OK;
+	if (c->parked || any_in_flight(c) || !c->d_pool.p || !c->cls[0].ready) return BWB_OK; /* (the pool and the list scratch must be idle: next chance at the next idle submit) */
+	if (c->dstream) HIPCHK(hipStreamSynchronize(c->dstream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	int K = DTAB_KMAX;
+	if (getenv("BWB_DTAB_K")) K = std::max(1, std::min(DTAB_KMAX, atoi(getenv("BWB_DTAB_K"))));
+	if (c->dtab_K) { c->d_dtab_ent.release(); c->d_dtab_pool.release(); c->dtab_K = 0; } /* (another alphabet) */
+	return c->pos32 ? build_dtab_t<uint32_t>(c, K) : build_dtab_t<uint64_t>(c, K);
+}
+
 /* BWB_LAUNCH_LOG: what ONE launch did - its HIP-event time and the counters it added (buckets fetched, heap entries stored / loaded, records
  * loaded) - so that per-dispatch PMC counters (tools/pmc_traffic.sh) can be priced launch by launch, slices and the draining launch apart */
 static int log_launch(bwb_hip_ctx *c, const char *kernel, int k, int si, bool drains, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
@@ -698,10 +790,10 @@ static int launch_calc_d(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 	HIPCHK(hipEventRecord(e0, st));
 	if (c->pos32)
 		hipLaunchKernelGGL(kl_calc_d<uint32_t>, dim3(grid), dim3(LANE_BLOCK), lds, st, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
-		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>());
+		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>(), dtab_of<uint32_t>(c));
 	else
 		hipLaunchKernelGGL(kl_calc_d<uint64_t>, dim3(grid), dim3(LANE_BLOCK), lds, st, c->ix, c->h_descs[si].b, wk, c->kp, sc.sc, dbgD, dbgDs,
-		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>());
+		                   s.maxlen + 1, (uint32_t)c->kp.seed_length + 1, c->d_stats.as<unsigned long long>(), dtab_of<uint64_t>(c));
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(e1, st));
 	if (c->dbg) {
@@ -817,6 +909,8 @@ static int submit(bwb_hip_ctx *c, int si, bool suspend) {
 	int rc = index_ready(c); /* (a context created with bwb_hip_ctx_create_async: its index upload may still be running) */
 	if (rc) return rc;
 	rc = ensure_class(c, 0);
+	if (rc) return rc;
+	rc = ensure_dtab(c, s.n_reads);
 	if (rc) return rc;
 	HIPCHK(hipStreamWaitEvent(c->stream, s.ev_up.e, 0));
 	const bool ahead = c->calcd_ahead > 0 && s.n_reads != 0;

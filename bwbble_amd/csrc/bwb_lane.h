@@ -506,11 +506,117 @@ template <typename P> __device__ __forceinline__ void list_flush_buf(const ListW
 }
 
 /* ============================================================================================
+ * The calculate_d table (round 6).  The first K steps of calculate_d (inexact_match.c:171-254) depend on nothing but the index and the LAST K
+ * bases of the sequence: the interval list, the restart count z, the summed width of the last step and the K bytes {min(z,127) | width-equal}
+ * after K steps are a function of that K-mer.  At GRCh37 scale those steps are where the lists are long - every code string with one or two
+ * IUPAC codes that is compatible with the bases occurs somewhere in 6.85 G rows until the suffix is about 16 long - and hold most of
+ * kl_calc_d's rank visits.  The table holds that state for all 4^K K-mers (K = 12: 16.7 M entries of 32 bytes + their interval lists), built
+ * once per context, level by level: the state of a k-mer is ONE step from the state of its (k-1)-mer (k_dtab_level), so the whole table
+ * costs about as much as calculate_d of the 4^K last steps.  kl_calc_d starts a read (and its seed) from the table; what it then computes,
+ * stores and hands to kl_search is bit for bit what the K steps would have produced.  288 GB of HBM are what makes this a table.
+ *
+ * Entry (two uint4): a = { list offset low 32 bits, offset bits 32..39 | z << 8 | valid << 15 | T << 16, nm (summed width of step K-1, the
+ * 32-bit wrap of the reference's int), rank-block visits of the K steps by the SURVEY 8(d) rule }, b = the K bytes (12 at most).
+ * An entry is invalid when a list on the way outgrew the build's buffers: such a read takes the ordinary path. */
+#define DTAB_KMAX 12
+template <typename P> struct DTab {
+	const uint4 *ent;       /* [4^K][2]; NULL: no table */
+	const Intv<P> *pool;
+	int K;
+};
+__device__ __forceinline__ uint32_t dtab_T(const uint4 a) { return a.y >> 16; }
+__device__ __forceinline__ bool dtab_valid(const uint4 a) { return (a.y >> 15) & 1u; }
+__device__ __forceinline__ uint32_t dtab_z(const uint4 a) { return (a.y >> 8) & 127u; }
+__device__ __forceinline__ unsigned long long dtab_off(const uint4 a) { return (unsigned long long)a.x | ((unsigned long long)(a.y & 255u) << 32); }
+
+/* one level of the table: entry `id` of level k (k-mer = its (k-1)-mer `id mod 4^(k-1)` followed by base `id >> 2(k-1)`) from the entries of
+ * level k-1.  One k-mer per lane; the parent's list is read in place, the children go to the lane's list scratch (kl_calc_d's, both halves)
+ * and from there to the level's pool at an offset taken from `bump`. */
+template <typename P>
+__global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void k_dtab_level(DevIndex ix, int multiref, int level, const uint4 *pent, const Intv<P> *ppool, uint4 *oent, Intv<P> *opool,
+                                                                                  unsigned long long *bump, unsigned long long pool_cap, LaneScratch sc) {
+	extern __shared__ __align__(16) unsigned char smem_[];
+	const LdsBytes smem = (LdsBytes)(uintptr_t)(((uint32_t)(uintptr_t)(LdsBytes)smem_ + 127u) & ~127u);
+	P *s_base = (P *)smem;
+	const int lane = (int)(threadIdx.x & 63u);
+	LdsBytes wlds = smem + CALCD_WAVES_OFF + (threadIdx.x >> 6) * WAVE_LDS_BYTES_NU(CALCD_NU);
+	Lds<u32x4> stage = (Lds<u32x4>)wlds, zero_row = (Lds<u32x4>)(smem + CALCD_ZERO_OFF);
+	const Lds<P> sb = (Lds<P>)smem;
+	if (threadIdx.x < 32) ((Lds<uint32_t>)zero_row)[threadIdx.x] = 0u;
+	load_base<P>(s_base, ix);
+	const uint32_t slot = blockIdx.x * LANE_BLOCK + threadIdx.x;
+	Intv<P> *lbuf = (Intv<P> *)sc.lists_d + (size_t)slot * 2 * sc.lcap;
+	const int cap = (int)(2 * sc.lcap);
+	const uint4 *__restrict__ buckets = ix.buckets;
+	const P last_row = (P)(ix.length - 1);
+	const unsigned long long n_tasks = 1ull << (2 * level), nl = (unsigned long long)gridDim.x * LANE_BLOCK;
+	const unsigned long long pmask = (1ull << (2 * (level - 1))) - 1ull;
+	for (unsigned long long base = 0; base < n_tasks; base += nl) { /* (whole waves iterate together: the gather is a wave's work) */
+		const unsigned long long id = base + slot;
+		const bool have = id < n_tasks;
+		const unsigned long long pid = have ? (id & pmask) : 0ull;
+		const int c = (int)(id >> (2 * (level - 1))) & 3;
+		const uint4 pa = pent[2 * pid], pb = pent[2 * pid + 1];
+		const bool pvalid = have && dtab_valid(pa);
+		const Intv<P> *plist = ppool + dtab_off(pa);
+		int T = pvalid ? (int)dtab_T(pa) : 0, s = 0;
+		ListW<P> nx; nx.T = 0; nx.tL = nx.tU = 0; nx.fL = nx.fU = 0;
+		uint32_t nm = 0, r_vis = 0, nbk = 0;
+		bool ovf = false;
+		while (wany(s < T)) {
+			const bool need = s < T;
+			Intv<P> iv; iv.L = 0; iv.U = 0;
+			if (need) iv = plist[s];
+			KidCtx<P> kc;
+			uint32_t ne = wave_children<P, CALCD_NU>(buckets, last_row, need, iv.L, iv.U, false, sb, stage, zero_row, lane, nbk, kc);
+			if (need) {
+				r_vis += (uint32_t)kc.nvis;
+				ne &= multiref ? member_mask(c) : single_mask_codes(c);
+				if (list_full<P>(nx, cap)) { ovf = true; T = 0; ne = 0; }
+				while (ne) { /* ascending code order == nucl_bases_table order (io.h:102-106) */
+					const int j = __ffs((int)ne) - 1;
+					ne &= ne - 1;
+					P L, U;
+					kid_get<P>(kc, sb, j, L, U);
+					nm += (uint32_t)(U - L + 1);
+					list_add<P>(nx, lbuf, 0, L, U, cap);
+				}
+				s++;
+			}
+		}
+		if (have) {
+			bool valid = pvalid && !ovf;
+			uint32_t z = dtab_z(pa);
+			int newT = nx.T;
+			P tL = nx.tL, tU = nx.tU;
+			if (newT == 0) { newT = 1; tL = 0; tU = last_row; z++; nm = (uint32_t)ix.length; } /* no matches: restart with the full interval (:240-244) */
+			const int k = level - 1; /* the D index of this step */
+			const uint32_t byte = (z > 127u ? 127u : z) | ((k > 0 && nm == pa.z) ? 0x80u : 0u);
+			unsigned long long off = 0;
+			if (valid) {
+				off = atomicAdd(bump, (unsigned long long)newT);
+				if (off + (unsigned long long)newT > pool_cap) valid = false;
+			}
+			if (valid) {
+				Intv<P> *dst = opool + off;
+				for (int t = 0; t + 1 < newT; t++) dst[t] = lbuf[t];
+				Intv<P> tl; tl.L = tL; tl.U = tU;
+				dst[newT - 1] = tl;
+			}
+			uint32_t db[3] = { pb.x, pb.y, pb.z };
+			db[k >> 2] = (db[k >> 2] & ~(255u << (8 * (k & 3)))) | (byte << (8 * (k & 3)));
+			oent[2 * id] = make_uint4((uint32_t)off, (uint32_t)(off >> 32) | (z << 8) | ((valid ? 1u : 0u) << 15) | ((uint32_t)newT << 16), nm, pa.w + r_vis);
+			oent[2 * id + 1] = make_uint4(db[0], db[1], db[2], 0u);
+		}
+	}
+}
+
+/* ============================================================================================
  * k_calc_d (one read per lane)
  * ========================================================================================== */
 template <typename P>
 __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(DevIndex ix, Batch b, Work wk, KParams kp, LaneScratch sc, int32_t *dbgD, int32_t *dbgDs,
-                                                        uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats) {
+                                                        uint32_t dbg_ld, uint32_t dbg_lds, unsigned long long *stats, DTab<P> dt) {
 	extern __shared__ __align__(16) unsigned char smem_[];
 	const LdsBytes smem = (LdsBytes)(uintptr_t)(((uint32_t)(uintptr_t)(LdsBytes)smem_ + 127u) & ~127u); /* (rows of the staging area are 128-byte aligned: RowRef; the host asks for 128 bytes more) */
 	P *s_base = (P *)smem;
@@ -547,6 +653,37 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 	unsigned long long vis = 0;
 	uint32_t r_vis = 0, n_bkt = 0;
 	const uint8_t *seq = b.reads;
+	const Intv<P> *curb = lbase; /* the current list: one half of the lane's buffer - or, for the step that follows a table lookup, the table's own list */
+	/* A phase (the read, then its seed) starts from the calculate_d table when its last K bases are four-letter ones: the K bytes go to the
+	 * records (and, for the read itself, the bases), z, the summed width of step K-1 and the visit count are taken over, and the step K reads
+	 * the entry's list in place.  Not with the debug arrays (they want every step's width: bwb_hip_calc_d). */
+	auto from_table = [&]() -> bool {
+		if (!dt.ent || dbgD || plen <= dt.K) return false;
+		unsigned long long idx = 0;
+		bool ok = true;
+		for (int t = 0; t < dt.K; t++) { const uint32_t ch = seq[plen - 1 - t]; ok &= ch <= 3u; idx |= (unsigned long long)(ch & 3u) << (2 * t); }
+		if (!ok) return false;
+		const uint4 ea = dt.ent[2 * idx], eb = dt.ent[2 * idx + 1];
+		const int T = (int)dtab_T(ea);
+		if (!dtab_valid(ea) || T + 15 > cap) return false;
+		uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
+		const uint32_t dbw[3] = { eb.x, eb.y, eb.z };
+		for (int k = 0; k < dt.K; k++) {
+			rec_put(rec, rec_count((uint32_t)len), phase ? 8 : 0, phase ? k + (len - kp.seed_length) : k, (dbw[k >> 2] >> (8 * (k & 3))) & 255u);
+			if (!phase) { /* (as at the end of a computed position, below) */
+				const int i1 = k + 1;
+				bacc |= (uint32_t)seq[len - 1 - k] << (4 * (i1 & 3));
+				if ((i1 & 3) == 3 || i1 == len) { *(uint16_t *)(rec + REC_BYTES * (i1 >> 2) + 6) = (uint16_t)bacc; bacc = 0; }
+			}
+		}
+		z = (int)dtab_z(ea); prev_nm = (int32_t)ea.z; nm = 0; r_vis += ea.w;
+		curb = dt.pool + dtab_off(ea); curT = T; s = 0; cg = -1; cursel = 0; nx.T = 0;
+		{ const Intv<P> tl = curb[T - 1]; cL = tl.L; cU = tl.U; }
+		if (T >= 2) nxi = curb[0];
+		nxi_valid = T >= 2;
+		r = plen - 1 - dt.K; c = seq[r]; cnext = r >= 1 ? seq[r - 1] : 4;
+		return true;
+	};
 
 	for (;;) {
 		if (!active && !done) {
@@ -565,7 +702,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 				}
 				c = len > 0 ? seq[len - 1] : 4; cnext = len > 1 ? seq[len - 2] : 4;
 				cL = 0; cU = last_row; curT = 1; nxi_valid = false; cg = -1;
-				nx.T = 0;
+				nx.T = 0; curb = lbase;
 				active = len > 0;
 				if (!(kp.seed_length && len > kp.seed_length)) {
 					/* D_seed is only computed when len > seed_length (inexact_match.c:141-143); otherwise the reference reads whatever
@@ -579,6 +716,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 				if (active && kp.use_precalc) /* -P: a read with an N in the last 12 bases of rc is dropped before calculate_d (inexact_match.c:129-136) */
 					for (int k = 0; k < PRECALC_LEN; k++) if (seq[k] > 3) active = false;
 				if (!active) { b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = 0; b.status[rid] = ST_OK; }
+				else (void)from_table();
 			}
 		}
 		if (wall(done)) break;
@@ -594,7 +732,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 				if (s == curT - 1) { iL = cL; iU = cU; }
 				else if (nxi_valid) { iL = nxi.L; iU = nxi.U; } /* the new list's first interval (registers) */
 				else if ((s >> 2) == cg) { iL = IR::lo(gw); iU = IR::hi(gw); } /* from the group fetched ahead of an earlier iteration's gather */
-				else { const Intv<P> v = (lbase + cursel * cap)[s]; iL = v.L; iU = v.U; asm volatile("" :: "v"(iL), "v"(iU)); } /* (never in the steady state: waited for inside the branch) */
+				else { const Intv<P> v = curb[s]; iL = v.L; iU = v.U; asm volatile("" :: "v"(iL), "v"(iU)); } /* (never in the steady state: waited for inside the branch) */
 			}
 		}
 		{ /* the group of the interval of the position's NEXT iteration, when that is one of the list in memory and not in the cached group:
@@ -604,7 +742,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 			const unsigned long long mw = wballot(want);
 			/* (not under `if (mw)`: a branch around the in-place loads makes the compiler merge a loaded and a not-loaded version of the four
 			 * registers behind it - copies of registers that are in flight; with an empty mask the loads are no-ops) */
-			const Intv<P> *g = lbase + cursel * cap + ((s + 1) & ~3);
+			const Intv<P> *g = curb + ((s + 1) & ~3);
 			IR::fetch(g0, g, mw); IR::fetch(g1, g + 1, mw); IR::fetch(g2, g + 2, mw); IR::fetch(g3, g + 3, mw);
 			cg = want ? (s + 1) >> 2 : cg;
 		}
@@ -633,7 +771,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 		if (c > 3 || s >= curT) {
 			/* position finished: swap lists (inexact_match.c:234-237) */
 			if (c <= 3) list_flush_buf<P>(nx, wb, lbase, cursel ^ 1, cap);
-			cursel ^= 1;
+			cursel ^= 1; curb = lbase + cursel * cap;
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
 			if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers - list_add -, not from what this step has just stored) */
 			nx.T = 0; s = 0; cg = -1;
@@ -667,6 +805,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 					phase = 1; plen = kp.seed_length; r = plen - 1; z = 0; prev_nm = 0;
 					cL = 0; cU = last_row; curT = 1;
 					c = seq[r]; cnext = r >= 1 ? seq[r - 1] : 4;
+					(void)from_table();
 				} else {
 					b.dbuf[(size_t)rid * b.dstride + b.dstride - 4] = (uint8_t)(cntN > 255 ? 255 : cntN);
 					*(uint32_t *)(b.dbuf + (size_t)rid * b.dstride + b.dstride - 8) = r_vis; /* work done for this read: a cheap predictor of search cost */

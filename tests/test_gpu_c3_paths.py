@@ -30,7 +30,7 @@ def mid(built, tmp_path_factory):
     return d, fa
 
 
-@pytest.mark.parametrize("extra_env", [{}, {"BWB_SLICE_ITERS": "120"}])
+@pytest.mark.parametrize("extra_env", [{}, {"BWB_SLICE_ITERS": "120"}, {"BWB_DTAB": "1", "BWB_DTAB_K": "9"}])  # (the last: the calculate_d table across superblock rows)
 def test_superblock_rows_and_packed_high_bits(mid, extra_env):
     d, fa = mid
     bw.build(testlib=True)

@@ -211,6 +211,44 @@ def test_calc_d_queued_ahead_on_a_second_stream_is_exact(mid, oracle, monkeypatc
     ctx.close()
 
 
+@pytest.mark.parametrize("env", [{"BWB_DTAB": "1", "BWB_DTAB_K": "8"}, {"BWB_DTAB": "1", "BWB_DTAB_K": "12", "BWB_POOL_GB": "3"},
+                                 {"BWB_DTAB": "1", "BWB_DTAB_K": "5", "BWB_FORCE_POS64": "1", "BWB_CALCD_AHEAD": "2"}])
+def test_calculate_d_table_is_exact(mid, oracle, monkeypatch, env):
+    """The calculate_d table (bwb_lane.h: DTab): kl_calc_d starts a read - and its seed - from the state after the first K steps, looked up by
+    the last K bases.  Same bytes, same rank-visit / pop / push counters as the oracle (any difference in a D byte changes the pruning), for the
+    multi-genome alphabet, -S (its own table), -P, ragged lengths around K, reads with N among the last K bases; and the table really is
+    used: fewer buckets fetched by kl_calc_d than without it, the same visits."""
+    d, fa = mid
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx = bw.Context(fa + ".bwt")
+    idx = oracle.load_index(fa + ".bwt")
+    seqs, lens = synth_reads(fa, str(d / "dtab.fq"), 6000, 100, 61, sub=2.0, indel=1.0, npct=1.0)
+    lens = lens.copy()
+    K = int(env["BWB_DTAB_K"])
+    for j, ln in enumerate([K - 1, K, K + 1, K + 2, 13, 32, 33, 44, 45, 57]):   # around K, around the seed length (32: its own phase), 45 = 32 + 13
+        lens[j::97] = max(1, ln)
+    seqs = seqs.copy()
+    seqs[5::53, 3] = 4                      # an N among the read's first bases (the seed's table lookup sees the bases 20..31)
+    for i in range(7, len(lens), 41):
+        seqs[i, max(0, int(lens[i]) - 4)] = 4  # an N among the last K bases: the read takes the ordinary path, its seed may not
+    st = check(ctx, oracle, idx, ["-n", "3"], seqs, lens)
+    table_buckets, table_visits = st.bucket_loads_calc_d, st.visits_calc_d
+    check(ctx, oracle, idx, ["-n", "0"], seqs[:2000], lens[:2000])
+    check(ctx, oracle, idx, ["-S", "-n", "2"], seqs[:3000], lens[:3000])       # another alphabet: the table is rebuilt
+    sel = np.where(lens[:3000] >= 13)[0]                                       # (-P: reads shorter than 12 are not representable, align.c:174-186)
+    check(ctx, oracle, idx, ["-P", "-n", "2"], seqs[sel], lens[sel])           # back to the multi-genome one
+    check(ctx, oracle, idx, ["-n", "3", "-l", "20", "-k", "1"], seqs[:3000], lens[:3000])
+    check(ctx, oracle, idx, ["-n", "2", "-l", "0"], seqs[:2000], lens[:2000])  # no seed
+    ctx.close()
+    monkeypatch.setenv("BWB_DTAB", "0")
+    ctx = bw.Context(fa + ".bwt")
+    st0 = check(ctx, oracle, idx, ["-n", "3"], seqs, lens)
+    ctx.close()
+    assert st0.visits_calc_d == table_visits
+    assert table_buckets < st0.bucket_loads_calc_d, (table_buckets, st0.bucket_loads_calc_d)
+
+
 def test_streamed_results_are_published_before_the_host_reads_them(mid_ctx):
     """Long slices: a slot's parked reads finish INSIDE the next slot's slice, and the host fetches status, counts, offsets and
     the hit log on another stream while that kernel is still running.  The kernel publishes a read's results (release fence)
