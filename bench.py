@@ -269,6 +269,9 @@ def main():
                      "note": residency + "; `achieved` / `frac` count the bytes this layout has to move for the launch's rank visits, counted in-kernel: "
                              "128-byte buckets actually fetched (an L-1/U pair in one bucket is fetched once) + heap entries stored and loaded + "
                              "per-position records; `achieved_ref_layout_GBs` prices the same visits at the reference layout's 192 B (SURVEY 8d): a rate, not a fraction"},
+        "calculate_d_table": dict(ctx.dtab_info(), note="kl_calc_d starts a read and its seed from the state after the first K steps of calculate_d, looked up by the last K bases "
+                                  "(bit-identical records; DESIGN.md 3.4): `visits` stay the reference's count, the buckets of those steps are not fetched - kl_calc_d's device bytes and "
+                                  "`device_frac` count what it really moves; built once per context, outside the timed region"),
         "hits_batch0": int(off0[-1]), "rerun_reads": int(st.n_overflow_reads), "kernel_ms_of_step_ms": round(kern_ms / (dt * 1e3), 4),
         "setup_s": {"genome_index_reads": round(t_build, 1), "index_to_hbm": round(t_ctx, 1),
                     "index": (json.load(open(fa + ".index_stats.json")) if os.path.exists(fa + ".index_stats.json") else None)},

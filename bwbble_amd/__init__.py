@@ -21,7 +21,7 @@ EXPORTS = [
     "bwb_hip_align_batch", "bwb_hip_batch_upload", "bwb_hip_batch_run", "bwb_hip_batch_result", "bwb_hip_get_stats",
     "bwb_hip_calc_d", "bwb_hip_rank16", "bwb_hip_rank_bench", "bwb_hip_rank_bench_lane", "bwb_hip_set_sa", "bwb_hip_locate", "bwb_hip_locate_stats",
     "bwb_hip_reset_stats", "bwb_hip_slot_upload", "bwb_hip_slot_submit", "bwb_hip_slot_wait", "bwb_hip_slot_result", "bwb_hip_flush", "bwb_hip_abi_version", "bwb_hip_ctx_create_streamed", "bwb_hip_device_numa_node",
-    "bwb_hip_ctx_create_async", "bwb_hip_ctx_index_wait", "bwb_hip_setup_times",
+    "bwb_hip_ctx_create_async", "bwb_hip_ctx_index_wait", "bwb_hip_setup_times", "bwb_hip_dtab_info",
 ]
 ABI_VERSION = 3  # BWB_HIP_ABI_VERSION (include/bwbble_hip.h)
 MAX_SLOTS = 8  # BWB_MAX_SLOTS
@@ -95,6 +95,8 @@ def lib():
         L.bwb_hip_flush.argtypes = [C.c_void_p]
         L.bwb_hip_set_sa.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.bwb_hip_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.bwb_hip_dtab_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.bwb_hip_setup_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.bwb_hip_locate_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         _lib = L
     return _lib
@@ -264,6 +266,12 @@ class Context:
         out = np.zeros(len(rows), dtype=np.uint64)
         _chk(lib().bwb_hip_locate(self._h, rows.ctypes.data, len(rows), out.ctypes.data))
         return out
+
+    def dtab_info(self):
+        """the context's calculate_d table: {K (0: none), build seconds, bytes}"""
+        k, sec, nb = C.c_int(), C.c_double(), C.c_uint64()
+        _chk(lib().bwb_hip_dtab_info(self._h, C.byref(k), C.byref(sec), C.byref(nb)))
+        return {"K": k.value, "build_s": round(sec.value, 3), "GB": round(nb.value / 1e9, 2)}
 
     def locate_stats(self):
         """(rows, invPsi steps = rank-block visits, kernel ms) of the last locate()"""

@@ -366,6 +366,14 @@ extern "C" int bwb_hip_ctx_index_wait(bwb_hip_ctx *c, double *seconds) {
 	return BWB_OK;
 }
 
+extern "C" int bwb_hip_dtab_info(bwb_hip_ctx *c, int *K, double *build_seconds, uint64_t *bytes) {
+	if (!c) return fail(BWB_E_ARG, "dtab_info: null context");
+	if (K) *K = c->dtab_K;
+	if (build_seconds) *build_seconds = c->dtab_seconds;
+	if (bytes) *bytes = c->dtab_K ? c->d_dtab_ent.bytes + c->d_dtab_pool.bytes : 0;
+	return BWB_OK;
+}
+
 extern "C" int bwb_hip_setup_times(bwb_hip_ctx *c, double *index_seconds, double *pool_seconds, uint64_t *pool_bytes) {
 	if (!c) return fail(BWB_E_ARG, "setup_times: null context");
 	if (index_seconds) *index_seconds = c->idx_thread.joinable() ? -1.0 : c->idx_seconds; /* (-1: the upload is still running) */

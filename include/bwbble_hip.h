@@ -121,6 +121,10 @@ int bwb_hip_ctx_index_wait(bwb_hip_ctx *ctx, double *seconds);
 /* where a context's start-up time went: seconds of the index upload (-1 while it is running), seconds spent in the hipMalloc of the heap
  * chunk pool and the pool's size (any pointer may be NULL) */
 int bwb_hip_setup_times(bwb_hip_ctx *ctx, double *index_seconds, double *pool_seconds, uint64_t *pool_bytes);
+/* The calculate_d table of the context: the state of calculate_d (inexact_match.c:171-254) after its first K steps for every
+ * K-mer, from which kl_calc_d starts a read and its seed.  Built by the first slot_submit / batch_run whose batch has at least 200 000 reads
+ * (environment: BWB_DTAB=1 always, 0 never; BWB_DTAB_K: K, default and maximum 12); K = 0: none.  Results do not depend on it. */
+int bwb_hip_dtab_info(bwb_hip_ctx *ctx, int *K, double *build_seconds, uint64_t *bytes);
 void bwb_hip_ctx_destroy(bwb_hip_ctx *ctx);
 
 /* Replaces align_reads_inexact[_parallel] for one batch (inexact_match.c:25-168): calculate_d x2 +
