@@ -449,13 +449,14 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 	ScratchClass &s = c->cls[k];
 	uint32_t blocks, lcap, acap;
 	if (k == 0) {
-		/* Blocks (of four waves) per CU.  Both kernels are built for three (bwb_lane.h).  kl_search runs two when the parameters allow
-		 * more than three differences: every lane holds a read with its heap, and the stationary heap population of 196 608 reads
-		 * with -n 5 on 150 bp reads exceeds the 200 GB chunk pool (reads are then abandoned and re-run: 65 k reads/s against 122 k
-		 * with two blocks, profiles/r3_c5_variants.txt); with -n 3 the pool is 62 % full at three.  The choice can change only
-		 * while nothing is parked (the grid, and with it the pool geometry, is fixed for the life of a stream). */
+		/* Blocks (of four waves) per CU.  Both kernels are built for three (bwb_lane.h), and run three.  (Rounds 3-5 ran kl_search at two when
+		 * the parameters allow more than three differences: every lane holds a read with its heap, and the stationary heaps of 196 608 reads
+		 * with -n 5 on 150 bp reads overran the 200 GB chunk pool - reads were abandoned and re-run, 103 k reads/s against 224 k at two blocks,
+		 * profiles/r5_bench_line_c5_three_blocks.json.)  The choice can change only while nothing is parked (the grid, and with it the pool
+		 * geometry, is fixed for the life of a stream); BWB_BLOCKS_PER_CU overrides it. */
 		if (!s.ready || !c->parked) {
-			c->bpc_search = c->kp.max_diff > 3 ? std::min(2, LANE_WAVES_PER_SIMD) : LANE_WAVES_PER_SIMD;
+			c->bpc_search = LANE_WAVES_PER_SIMD; /* (round 6: also beyond three differences - with the gap entries halved, see bwb_lane.h `combined group`,
+			                                        the stationary heaps of 196 608 reads with -n 5 on 150 bp reads fill 60 % of the pool; rounds 3-5 ran two blocks there) */
 			c->bpc_calcd = CALCD_WAVES_PER_SIMD;
 			if (getenv("BWB_BLOCKS_PER_CU")) c->bpc_search = std::max(1, atoi(getenv("BWB_BLOCKS_PER_CU")));
 			if (getenv("BWB_KEEP")) c->keep = (uint32_t)std::max(0, atoi(getenv("BWB_KEEP")));

@@ -161,8 +161,10 @@ static void *gpu_worker(void *arg) {
 	 * (bwt_io.c), and while this thread already uploads its first chunk: that first slot_upload sizes and allocates the context's scratch
 	 * and its heap chunk pool (seconds of hipMalloc at GRCh37 scale, which rounds 3-5 paid AFTER the index upload); slot_submit waits for
 	 * the index by itself. */
-	if (bwb_hip_ctx_create_async(w->device, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, w->BWT->loader ? &w->BWT->blocks_ready : NULL, &ctx))
+	const int sync_create = getenv("BWB_SYNC_CREATE") != NULL; /* (A/B: rounds 3-5 - the index first, everything else behind it) */
+	if ((sync_create ? bwb_hip_ctx_create_streamed : bwb_hip_ctx_create_async)(w->device, hdr, w->BWT->C, w->BWT->bwt, w->BWT->O, w->BWT->loader ? &w->BWT->blocks_ready : NULL, &ctx))
 		bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
+	if (dbg) fprintf(stderr, "[bwb host] worker %d: context created at +%.3f s (%s)\n", w->gpu, wall() - tq, sync_create ? "index uploaded" : "index upload under way");
 	enum { NS = BWB_MAX_SLOTS }; /* chunks in flight: the heaviest reads of a chunk take several slices' time (they are parked and resumed), and
 	                                a slot can be uploaded again only when its chunk is complete */
 	chunk_t *in_slot[NS];

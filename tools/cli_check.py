@@ -21,6 +21,7 @@ out = fq + ".cli.aln"
 t = time.time()
 log = subprocess.run([bw.HOST_BIN, "align"] + flags + [fa, fq, out], check=True, stdout=subprocess.PIPE, text=True).stdout
 print([l for l in log.splitlines() if l.startswith("GPUs:")][0], f"| process wall {time.time() - t:.1f} s")
+print("\n".join(l for l in log.splitlines() if l.startswith("start-up:")))
 
 
 def records(path, first, count):
