@@ -156,6 +156,7 @@ struct bwb_hip_ctx {
 	/* the calculate_d table (bwb_lane.h: DTab): entries and interval lists of all 4^K K-mers, built at the first large batch */
 	DevMem d_dtab_ent, d_dtab_pool;
 	int dtab_K = 0;                     /* 0: no table */
+	uint32_t dtab_nm1[4] = { 0, 0, 0, 0 }; /* the level-1 entries' summed widths (DTab::nm1) */
 	int dtab_multiref = -1;             /* the alphabet it was built for (-S has its own children) */
 	int dtab_mode = -1;                 /* BWB_DTAB: 0 never, 1 always, unset: when a batch has at least DTAB_MIN_READS reads */
 	bool dtab_failed = false;           /* a build did not fit its buffers: not tried again */
@@ -435,7 +436,10 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	if (getenv("BWB_POOL_GB") && *getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
 	if (want < ((size_t)256 << 20)) want = (size_t)256 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path: class 2 must still fit a read) */
 	want &= ~(size_t)(POOL_REGIONS * 4096 - 1);
-	if (c->d_pool.p && c->d_pool.bytes >= want) return BWB_OK;
+	/* (a pool within 15 % of what would be asked for now is kept: `want` moves by a slot's size with every upload and by the table's reserve
+	 * once that is built, and giving 170 GB back to the driver and taking them again costs five seconds - rounds 3-5 did that at every one of a
+	 * stream's first uploads, round 6's profiles/r6_ab_steps.txt session 3) */
+	if (c->d_pool.p && (c->d_pool.bytes >= want || (c->d_pool.bytes >= want / 20 * 17 && !getenv("BWB_POOL_GB")))) return BWB_OK;
 	if (c->parked) return BWB_OK; /* parked reads hold chunks of the present pool: keep it (the admission control copes) */
 	c->d_pool.release();
 	if (want > fr) return fail(BWB_E_HIP, "not enough device memory for the heap chunk pool");
@@ -692,6 +696,7 @@ template <typename P> static DTab<P> dtab_of(const bwb_hip_ctx *c) {
 	t.ent = use ? c->d_dtab_ent.as<uint4>() : nullptr;
 	t.pool = c->d_dtab_pool.as<Intv<P>>();
 	t.K = c->dtab_K;
+	for (int j = 0; j < 4; j++) t.nm1[j] = c->dtab_nm1[j];
 	return t;
 }
 
@@ -734,6 +739,12 @@ template <typename P> static int build_dtab_t(bwb_hip_ctx *c, int K) {
 		HIPCHK(hipStreamSynchronize(c->stream)); /* (the level is complete: its interval count) */
 		int rc = fetch(c, &total, bump.p, 8);
 		if (rc) return rc;
+		if (k == 1) { /* the first step's summed width by base: what a lookup after a restart compares the restart's width with */
+			uint4 e1[8];
+			rc = fetch(c, e1, ent_of[1]->p, sizeof(e1));
+			if (rc) return rc;
+			for (int j = 0; j < 4; j++) c->dtab_nm1[j] = e1[2 * j].z;
+		}
 		if (total > cap) {
 			if (c->dbg) fprintf(stderr, "[bwb] calculate_d table: level %d needs %llu intervals, the scratch holds %llu: no table\n", k, total, cap);
 			c->dtab_failed = true;

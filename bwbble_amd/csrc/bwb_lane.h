@@ -523,6 +523,7 @@ template <typename P> struct DTab {
 	const uint4 *ent;       /* [4^K][2]; NULL: no table */
 	const Intv<P> *pool;
 	int K;
+	uint32_t nm1[4];        /* summed width of the FIRST step by base (the level-1 entries' nm): the width-equal bit of a lookup that follows a restart */
 };
 __device__ __forceinline__ uint32_t dtab_T(const uint4 a) { return a.y >> 16; }
 __device__ __forceinline__ bool dtab_valid(const uint4 a) { return (a.y >> 15) & 1u; }
@@ -654,34 +655,43 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 	uint32_t r_vis = 0, n_bkt = 0;
 	const uint8_t *seq = b.reads;
 	const Intv<P> *curb = lbase; /* the current list: one half of the lane's buffer - or, for the step that follows a table lookup, the table's own list */
-	/* A phase (the read, then its seed) starts from the calculate_d table when its last K bases are four-letter ones: the K bytes go to the
-	 * records (and, for the read itself, the bases), z, the summed width of step K-1 and the visit count are taken over, and the step K reads
-	 * the entry's list in place.  Not with the debug arrays (they want every step's width: bwb_hip_calc_d). */
+	/* calculate_d is in the table's state - ONE interval, the whole index - at the start of a phase (the read, then its seed) and after every
+	 * restart (:240-244: no match, or an N in the read - for two reads in three at GRCh37 scale, every substitution is one).  When the next K
+	 * bases are four-letter ones and at least one position follows them, the K steps are looked up: the K bytes go to the records (z counted
+	 * on from the present z; for the read itself also the bases), z, the summed width of step K-1 and the visit count are taken over, and the
+	 * step after them reads the entry's list in place.  `r` = the position about to be processed.  Not with the debug arrays (they want every
+	 * step's width: bwb_hip_calc_d). */
 	auto from_table = [&]() -> bool {
-		if (!dt.ent || dbgD || plen <= dt.K) return false;
+		if (!dt.ent || dbgD || r < dt.K) return false;
 		unsigned long long idx = 0;
 		bool ok = true;
-		for (int t = 0; t < dt.K; t++) { const uint32_t ch = seq[plen - 1 - t]; ok &= ch <= 3u; idx |= (unsigned long long)(ch & 3u) << (2 * t); }
+		for (int t = 0; t < dt.K; t++) { const uint32_t ch = seq[r - t]; ok &= ch <= 3u; idx |= (unsigned long long)(ch & 3u) << (2 * t); }
 		if (!ok) return false;
 		const uint4 ea = dt.ent[2 * idx], eb = dt.ent[2 * idx + 1];
 		const int T = (int)dtab_T(ea);
 		if (!dtab_valid(ea) || T + 15 > cap) return false;
 		uint8_t *rec = b.dbuf + (size_t)rid * b.dstride;
 		const uint32_t dbw[3] = { eb.x, eb.y, eb.z };
-		for (int k = 0; k < dt.K; k++) {
-			rec_put(rec, rec_count((uint32_t)len), phase ? 8 : 0, phase ? k + (len - kp.seed_length) : k, (dbw[k >> 2] >> (8 * (k & 3))) & 255u);
+		for (int t = 0; t < dt.K; t++) {
+			const int k = plen - 1 - (r - t); /* the D index of position r - t */
+			const uint32_t tb = (dbw[t >> 2] >> (8 * (t & 3))) & 255u;
+			const uint32_t zz = (uint32_t)z + (tb & 127u);
+			uint32_t byte = (zz > 127u ? 127u : zz) | (tb & 128u);
+			/* (the table's first step has no width-equal bit - D[0] has none, :246 -; after a restart the step compares with the restart's width) */
+			if (t == 0 && k > 0 && dt.nm1[seq[r] & 3u] == (uint32_t)prev_nm) byte |= 128u;
+			rec_put(rec, rec_count((uint32_t)len), phase ? 8 : 0, phase ? k + (len - kp.seed_length) : k, byte);
 			if (!phase) { /* (as at the end of a computed position, below) */
 				const int i1 = k + 1;
-				bacc |= (uint32_t)seq[len - 1 - k] << (4 * (i1 & 3));
+				bacc |= (uint32_t)seq[len - i1] << (4 * (i1 & 3));
 				if ((i1 & 3) == 3 || i1 == len) { *(uint16_t *)(rec + REC_BYTES * (i1 >> 2) + 6) = (uint16_t)bacc; bacc = 0; }
 			}
 		}
-		z = (int)dtab_z(ea); prev_nm = (int32_t)ea.z; nm = 0; r_vis += ea.w;
+		z += (int)dtab_z(ea); prev_nm = (int32_t)ea.z; nm = 0; r_vis += ea.w;
 		curb = dt.pool + dtab_off(ea); curT = T; s = 0; cg = -1; cursel = 0; nx.T = 0;
 		{ const Intv<P> tl = curb[T - 1]; cL = tl.L; cU = tl.U; }
 		if (T >= 2) nxi = curb[0];
 		nxi_valid = T >= 2;
-		r = plen - 1 - dt.K; c = seq[r]; cnext = r >= 1 ? seq[r - 1] : 4;
+		r -= dt.K; c = seq[r]; cnext = r >= 1 ? seq[r - 1] : 4;
 		return true;
 	};
 
@@ -775,7 +785,8 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 			curT = (c > 3) ? 0 : nx.T; cL = nx.tL; cU = nx.tU;
 			if (curT >= 2) { nxi.L = nx.fL; nxi.U = nx.fU; } /* (the new list's first interval: from registers - list_add -, not from what this step has just stored) */
 			nx.T = 0; s = 0; cg = -1;
-			if (curT == 0) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
+			const bool restarted = curT == 0;
+			if (restarted) { /* no matches: restart with the full interval (inexact_match.c:240-244) */
 				cL = 0; cU = last_row; curT = 1; z++;
 				nm = (int32_t)(uint32_t)ix.length;
 			}
@@ -813,7 +824,7 @@ __global__ __launch_bounds__(LANE_BLOCK, CALCD_WAVES_PER_SIMD) void kl_calc_d(De
 					vis += r_vis;
 					active = false;
 				}
-			}
+			} else if (restarted) (void)from_table(); /* (the state is the table's again: the next K positions by lookup) */
 		}
 		/* the interval of the next iteration: the list's tail and a new list's first interval are in registers, the others come from the group cache */
 		nxi_valid = active && c <= 3 && s == 0 && curT >= 2;
