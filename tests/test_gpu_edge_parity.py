@@ -387,12 +387,13 @@ def fuzz_case(rng, d, fa, tag):
     return flags, seqs, lens
 
 
-@pytest.mark.parametrize("env,seed,cases", [({}, 5001, 28), ({"BWB_SLICE_ITERS": "90"}, 5002, 12)])
+@pytest.mark.parametrize("env,seed,cases", [({}, 5001, 28), ({"BWB_SLICE_ITERS": "90"}, 5002, 12), ({"BWB_DTAB": "1", "BWB_DTAB_K": "7"}, 5003, 16)])
 def test_fuzz_sweep_of_parameters_read_lengths_and_error_rates(mid, oracle, monkeypatch, env, seed, cases):
     """40 seeded cases of tools/fuzz_parity.py's generator inside the GPU suite: random -n/-o/-e/-l/-k/-M/-O/-E/-m, -S, -P,
     read lengths 24..200 with a second length interleaved, substitution / indel / N rates - 28 cases in one launch each, 12 with every
-    wave parked after 90 loop iterations (every read parked and resumed dozens of times).  Bytes, visits, pops and pushes equal to the
-    oracle's (serial reference: fresh_dseed = 0)."""
+    wave parked after 90 loop iterations (every read parked and resumed dozens of times), 16 (round 6) with the calculate_d table forced
+    (K = 7; rebuilt whenever a case switches the alphabet).  Bytes, visits, pops and pushes equal to the oracle's (serial reference:
+    fresh_dseed = 0)."""
     import random
     d, fa = mid
     for k, v in env.items():
