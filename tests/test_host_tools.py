@@ -426,6 +426,29 @@ def test_bwt_loader_refuses_an_inconsistent_header(built, golden, tmp_path):
         assert r.returncode != 0 and "load_bwt" in r.stdout, (field, r.returncode, r.stdout[-200:])
 
 
+def test_bwt_loader_refuses_a_header_that_promises_more_than_the_file_holds(built, golden, tmp_path):
+    """a CONSISTENT header of a huge index in front of a small file is refused on the file's size, before any array is sized from it
+    (the allocations used to come first - a crafted header drove an arbitrarily large malloc before it was rejected)"""
+    import struct
+    src = open(os.path.join(golden, "toy.fa.bwt"), "rb").read()
+    length = 1 << 44  # 16 T characters: 2 TB of bwt words, 17 TB of O rows
+    hdr = [length, (length + 7) // 8, (length + 31) // 32, (length + 127) // 128, 5]
+    path = tmp_path / "huge.bwt"
+    open(path, "wb").write(struct.pack("<5Q", *hdr) + src[40:])
+    r = subprocess.run([bw.HOST_BIN, "bwtcat", str(path), str(tmp_path / "o.bwt")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "Could not read BWT" in r.stdout and "allocate" not in r.stdout, (r.returncode, r.stdout[-200:])
+
+
+def test_aln_reader_refuses_a_record_longer_than_a_path(built, golden, tmp_path):
+    """aln_length comes from the file and indexes a 272-byte path in the record builders: beyond the reference's 8-bit field it is refused"""
+    import struct
+    rec = struct.pack("<i", 1) + struct.pack("<iQQiiii", 9, 10, 12, 3, 0, 0, 60000) + struct.pack("<i", 1) + struct.pack("<i", 0 | (60000 << 2))
+    path = tmp_path / "long.aln"
+    open(path, "wb").write(rec)
+    r = subprocess.run([bw.HOST_BIN, "alncat", str(path), str(tmp_path / "o.aln")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "not an ALN record" in r.stdout, (r.returncode, r.stdout[-200:])
+
+
 @pytest.mark.parametrize("aln", ["toy_n0.aln", "toy_n3.aln", "toy_n4gap.aln", "ragged_n5.aln", "toy_s4gap.aln", "short_n2_t1.aln", "gapo_o6.aln"])
 def test_aln_reader_and_writer_round_trip(built, golden, tmp_path, aln):
     """host/aln_io.c without a GPU.  The reference's loader fills aln_path in pair order (align.c:466-476), i.e. it holds the
