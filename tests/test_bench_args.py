@@ -41,7 +41,14 @@ def test_stored_pmc_profile_is_quoted_only_for_the_kernels_it_was_measured_on(mo
     a.steps = 20
     traffic, src = bench.measured_traffic(a, a.reads, "kl_search", dom)
     if pj["source_hash"] == bench.source_hash():
-        assert traffic == pj["kl_search"]["hbm_bytes_per_step"] * 20 / 21 and "NOT measured in this run" in src
+        pl = pj["kl_search"].get("per_launch")
+        if isinstance(pl, dict):  # (round 6) every dispatch priced on its own: the run's traffic is a sum over its slices and its draining launch
+            want = (20 * pl["slice"]["hbm_bytes_per_launch"] + 1 * pl["drain"]["hbm_bytes_per_launch"]) / 21
+            assert abs(traffic - want) < 1e-6 * want and "every dispatch priced on its own" in src
+            assert pl["slice"]["launches"] >= 8 and pl["drain"]["launches"] >= 1
+        else:
+            assert traffic == pj["kl_search"]["hbm_bytes_per_step"] * 20 / 21
+        assert "NOT measured in this run" in src
     else:
         assert traffic is None and "other kernel sources" in src
     monkeypatch.setattr(bench, "source_hash", lambda: "0" * 16)
