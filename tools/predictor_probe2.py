@@ -42,7 +42,7 @@ feats = {
     "min over steps 16..99 of log2 width (how narrow it ever gets)": lw[:, 16:ln].min(axis=1),
 }
 order_it = np.argsort(-it)
-for name_cut, cut in (("the heaviest 0.02 % (>= %.0f iterations)", 0.0002), ("the heaviest 0.1 %% (>= %.0f)", 0.001), ("the heaviest 1 %% (>= %.0f)", 0.01)):
+for name_cut, cut in (("the heaviest 0.02 %% (>= %.0f iterations)", 0.0002), ("the heaviest 0.1 %% (>= %.0f)", 0.001), ("the heaviest 1 %% (>= %.0f)", 0.01)):
     k = max(1, int(len(it) * cut))
     heavy = set(order_it[:k].tolist())
     print("\n== recall of " + (name_cut % it[order_it[k - 1]]) + f": {k} reads")
