@@ -476,8 +476,8 @@ static int ensure_class(bwb_hip_ctx *c, int k) {
 				const size_t need = ((fa.sharedSizeBytes + dyn + LDS_GRANULE - 1) / LDS_GRANULE) * LDS_GRANULE;
 				return (int)std::max<size_t>(1, LDS_CU_BYTES / need);
 			};
-			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true, true, true> : (const void *)kl_search<uint32_t, false, true, true>)
-			                          : (c->wide ? (const void *)kl_search<uint64_t, true, true, true> : (const void *)kl_search<uint64_t, false, true, true>); /* (the -S and the slice instantiations need no more) */
+			const void *kf = c->pos32 ? (c->wide ? (const void *)kl_search<uint32_t, true, true> : (const void *)kl_search<uint32_t, false, true>)
+			                          : (c->wide ? (const void *)kl_search<uint64_t, true, true> : (const void *)kl_search<uint64_t, false, true>); /* (the -S instantiations need no more) */
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, LANE_BLOCK, lane_lds(c)) == hipSuccess && occ >= 1) {
 				if (c->dbg && !s.ready) fprintf(stderr, "[bwb] kl_search: %d block(s) of %d threads fit a CU\n", occ, LANE_BLOCK);
 				c->bpc_search = std::min(c->bpc_search, std::min(occ, lds_fit(kf, lane_lds(c))));
@@ -867,11 +867,7 @@ static int launch_search(bwb_hip_ctx *c, int k, int si, const uint32_t *wl, uint
 	HIPCHK(hipEventRecord(e0, c->stream));
 	const SlotDesc *descs = c->d_descs.as<SlotDesc>();
 	unsigned long long *st = c->d_stats.as<unsigned long long>();
-	/* (a launch that drains runs the cooperative instantiation, bwb_lane.h COOP: idle lanes help through long exact-tail lists; BWB_NO_COOP: A/B) */
-	static const bool no_coop = getenv("BWB_NO_COOP") != nullptr;
-	const bool coop = !(suspend || slice_iters != 0) && !no_coop;
-#define LAUNCH_SEARCH(PT, W, M) do { if (coop) hipLaunchKernelGGL((kl_search<PT, W, M, true>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st); \
-	else hipLaunchKernelGGL((kl_search<PT, W, M, false>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st); } while (0)
+#define LAUNCH_SEARCH(PT, W, M) hipLaunchKernelGGL((kl_search<PT, W, M>), dim3(grid), dim3(LANE_BLOCK), lds, c->stream, c->ix, descs, wk, c->kp, s.sc, st)
 	const bool multi = c->kp.multiref != 0;
 	if (c->pos32 && !c->wide) { if (multi) LAUNCH_SEARCH(uint32_t, false, true); else LAUNCH_SEARCH(uint32_t, false, false); }
 	else if (c->pos32) { if (multi) LAUNCH_SEARCH(uint32_t, true, true); else LAUNCH_SEARCH(uint32_t, true, false); }

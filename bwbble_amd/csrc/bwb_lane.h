@@ -1172,14 +1172,7 @@ enum { H_ITER = 0, H_POP, H_POP_FROM_MIRROR, H_POP_GAPPED, H_PRUNED, H_HIT, H_EX
  * belongs to an earlier slot than the reads its wave starts next, hence the per-lane `myslot` and the slot table. */
 /* MULTI: the multi-genome alphabet (is_multiref; false = -S).  A template parameter, not a look at MULTI: the choice sits in every
  * trip of the child loops (the -S children are rows 1..4 mapped back to their codes), and the loop is bound by instruction issue. */
-/* COOP (round 6): the instantiation that DRAINS (the last launch of a stream, the one-batch interface, the re-run classes).  A drain ends
- * with a few reads per wave, and what those do most is the multi-interval exact tail - for the reads that run into max_entries hundreds of
- * one-mismatch candidates, each walking a list of up to a thousand intervals down the read, one interval per iteration of one lane, 3 us
- * each.  The intervals of one step are independent (exact_match.c:88-110: children of interval s are appended after those of s - 1), so the
- * lanes of the wave that have no read left each take one of the owner's following intervals through the SAME gather (it is the wave's
- * anyway), rank it and leave the children in their LDS rows; the owner appends them in list order.  One iteration then moves up to 64
- * intervals of one read.  Slices (COOP = false) are the code they were: with every lane busy there is nobody to help. */
-template <typename P, bool WIDE, bool MULTI, bool COOP>
+template <typename P, bool WIDE, bool MULTI>
 __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(DevIndex ix, const SlotDesc *__restrict__ descs, Work wk, KParams kp, LaneScratch sc, unsigned long long *stats) {
 	/* The kernel arguments that only rare paths use (starting, parking and finishing a read, the statistics) are read from the kernarg
 	 * segment where they are used - the pointer goes through an empty asm, so the loads cannot be hoisted out of the loop - instead of
@@ -1542,31 +1535,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		/* the interval of the step's NEXT iteration, when it is one of the list in memory (not its tail, which is in registers): fetched
 		 * now, under this iteration's gather (round 3 fetched it at the end of the iteration and used it at the start of the next) */
 		if (ex && s + 1 < curT - 1) nxi = (lbase + (cursel ? lcap : 0))[s + 1];
-		/* ---- (COOP) the wave's idle lanes take the intervals that follow the owner's current one (not its tail: that one lives in registers) ---- */
-		bool helper = false;
-		uint32_t co_owner = 0, co_n = 0;
-		unsigned long long co_idle = 0ull;
-		if (COOP) {
-			const int co_rem = ex ? curT - 2 - s : 0; /* intervals of the current list in memory after this one */
-			const unsigned long long co_m = wballot(co_rem >= 1);
-			co_idle = wballot(!active);
-			if ((co_m != 0ull) & (co_idle != 0ull)) { /* (wave-uniform; the helpers' loads are waited for in here, ahead of the in-place prefetches) */
-				co_owner = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)co_m) - 1);
-				const int rem_o = __builtin_amdgcn_readlane(co_rem, (int)co_owner);
-				const int nidle = __popcll(co_idle);
-				co_n = (uint32_t)(rem_o < nidle ? rem_o : nidle);
-				const uint64_t lp = (uint64_t)(uintptr_t)(lbase + (cursel ? lcap : 0));
-				const uint32_t lp_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lp, (int)co_owner), lp_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(lp >> 32), (int)co_owner);
-				const int s_o = __builtin_amdgcn_readlane(s, (int)co_owner);
-				const uint32_t q = (uint32_t)__popcll(co_idle & ((1ull << lane) - 1ull));
-				helper = !active && q < co_n;
-				if (helper) {
-					const Intv<P> v = ((const Intv<P> *)(uintptr_t)(((uint64_t)lp_hi << 32) | lp_lo))[s_o + 1 + (int)q];
-					iL = v.L; iU = v.U; need_rank = true;
-					asm volatile("" :: "v"(iL), "v"(iU));
-				}
-			}
-		}
 		h.prefetch(pf_top, pf_hdr); /* (the lanes have met again: see prefetch128) */
 
 #ifdef BWB_HIST
@@ -1588,7 +1556,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		int cr = 4;
 		const unsigned long long rmask = wballot(need_rank);
 		const int nreq = __popcll(rmask);
-		const bool want_rec = (need_rank && !(COOP && helper)) || (from_pop && rd_len < kq.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
+		const bool want_rec = need_rank || (from_pop && rd_len < kq.seed_length); /* (a finished entry, i == 0, of a read shorter than the seed still meets the seed bound, :324-328) */
 		/* The record of the entry's position (D[i-1], D[i-2] | D_seed pair | seq[len - widx]: bwb_kernels.h) - the one in registers when its tag
 		 * matches, else one load.  It is only ISSUED here, in place (prefetch128), and unpacked after the rank: round 3 unpacked it on the spot
 		 * - a flat load, which the gather's wait for its exchange array waits for as well - so a wave sat out the record's round trip before
@@ -1627,17 +1595,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 		/* -S (O_actg_alphabet bwt.c:440-463): only A, G, C, T exist as children, pushed in that order (:434-504 with alphabet_size 5):
 		 * child rows 1..4 stand for the codes 15, 3, 7, 1 */
 		if (!MULTI) ne = (((ne >> 15) & 1u) << 1) | (((ne >> 3) & 1u) << 2) | (((ne >> 7) & 1u) << 3) | (((ne >> 1) & 1u) << 4);
-		if (COOP && co_n != 0u) { /* a helper leaves what its interval gives for the owner's read base: the member children's mask, its visits, its base rows */
-			const int cr_o = __builtin_amdgcn_readlane(cr, (int)co_owner);
-			Lds<uint32_t> xw = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF); /* (the gather's exchange array: free until the next gather) */
-			if (helper) {
-				const uint32_t nmh = cr_o > 3 ? 0u : (ne & (MULTI ? member_mask(cr_o) : 2u << cr_o));
-				xw[2 * lane] = nmh | ((uint32_t)kc.nvis << 16);
-				xw[2 * lane + 1] = ((uint32_t)(uintptr_t)kc.baseL & 0xFFFFu) | ((uint32_t)(uintptr_t)kc.baseU << 16);
-			}
-			asm volatile("" ::: "memory");
-			__builtin_amdgcn_wave_barrier();
-		}
 		uint32_t st_cnt = 0; /* heap entries this lane stores in this iteration */
 		auto kid = [&](int j, P &L, P &U) { kid_get<P>(kc, sb, MULTI ? j : (int)((0x173Fu >> (4 * (j - 1))) & 15u), L, U); };
 		STAMP(3);
@@ -1929,31 +1886,6 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 					list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap);
 				}
 				s += isN ? 0 : 1;
-				bool co_used = false;
-				if (COOP && co_n != 0u && lane == (int)co_owner && !isN && !ovf) { /* the helpers' intervals, in list order */
-					Lds<uint32_t> xw = (Lds<uint32_t>)((LdsBytes)stage + WAVE_XCH_OFF);
-					unsigned long long hm = co_idle;
-					for (uint32_t q = 0; q < co_n; q++) {
-						const int hl = __ffsll((long long)hm) - 1;
-						hm &= hm - 1ull;
-						const uint32_t w0 = xw[2 * hl], w1 = xw[2 * hl + 1];
-						if (!seeding) r_vis_s += w0 >> 16;
-						if (list_full<P>(nx, lcap)) { ovf = true; break; }
-						KidCtx<P> kh;
-						kh.R = row_ref(stage, (uint32_t)hl); kh.baseL = (Lds<P>)(uintptr_t)(w1 & 0xFFFFu); kh.baseU = (Lds<P>)(uintptr_t)(w1 >> 16); kh.nvis = 0; kh.qL = kh.qU = false;
-						uint32_t nmh = w0 & 0xFFFFu;
-						while (nmh) {
-							const int j = __ffs((int)nmh) - 1;
-							nmh &= nmh - 1;
-							P cl, cu;
-							kid_get<P>(kh, sb, MULTI ? j : (int)((0x173Fu >> (4 * (j - 1))) & 15u), cl, cu);
-							nxw += (uint32_t)(cu - cl + 1);
-							list_add<P>(nx, lbase, cursel ? 0 : 1, cl, cu, lcap);
-						}
-						s++;
-					}
-					co_used = true;
-				}
 				const bool swap = !isN && !ovf && s >= curT;
 				/* the list's swap; an N ends the tail with an empty list (curT = 0) */
 				cursel = swap ? !cursel : cursel;
@@ -1970,7 +1902,7 @@ __global__ __launch_bounds__(LANE_BLOCK, LANE_WAVES_PER_SIMD) void kl_search(Dev
 				/* the interval of the next iteration, when it is not the list's tail (which is in registers): within a step it is on its way
 				 * since the start of this iteration; the first interval of a NEW list was kept in registers by list_add (round 4's first
 				 * version loaded what this step had just stored: the wait for it, at the start of the next iteration, was 10 % of the loop) */
-				nxi_valid = !ovf && !exact_done && s != curT - 1 && !co_used; /* (after a cooperative step the interval fetched ahead is not the next one) */
+				nxi_valid = !ovf && !exact_done && s != curT - 1;
 			}
 			STAMP(6);
 			if (exact_done && !ovf && seeding) {
