@@ -208,10 +208,7 @@ static void *gpu_worker(void *arg) {
 	if (bwb_hip_flush(ctx) || bwb_hip_get_stats(ctx, &st)) bwb_die("align_reads_inexact_gpu: GPU %d: %s", w->device, bwb_hip_last_error());
 	w->total = st;
 	w->kernel_ms = st.ms_calc_d + st.ms_search;
-	/* The context - 230 GB of device memory at GRCh37 scale - is NOT torn down piece by piece: `align` is about to exit, and handing 170 GB
-	 * back through hipFree costs over a second that the process's exit does not (align_reads ends with _exit once the .aln is closed).
-	 * BWB_FULL_TEARDOWN=1: the orderly way (sanitizer runs, a caller that links align_reads into a longer-lived program). */
-	if (getenv("BWB_FULL_TEARDOWN")) bwb_hip_ctx_destroy(ctx);
+	bwb_hip_ctx_destroy(ctx);
 	if (dbg) fprintf(stderr, "[bwb host] worker %d: done %.3f s\n", w->gpu, wall() - tq);
 	return NULL;
 }
@@ -342,10 +339,6 @@ int align_reads(char *fastaFname, char *readsFname, char *alnsFname, aln_params_
 	t = wall();
 	align_reads_inexact_gpu_stream(BWT, readsFname, params, alnsFname, n_gpus);   /* the seam: align.c:72-76 */
 	printf("Total read alignment time (index and read loading overlapped): %.2f sec\n", wall() - t);
-	if (!getenv("BWB_FULL_TEARDOWN")) { /* the .aln is written and closed (align_reads_inexact_gpu_stream): nothing is left to do but give memory back, which exit does */
-		fflush(NULL);
-		_exit(0);
-	}
 	free_bwt(BWT);
 	free(bwtFname);
 	return 0;
