@@ -432,6 +432,9 @@ static int ensure_pool(bwb_hip_ctx *c) {
 	const size_t index_mb = (size_t)(c->ix.nblk >> 13) + 1;
 	const size_t per_lane = ((size_t)c->keep << 10) + std::min<size_t>((size_t)1536 << 10, index_mb << 9);
 	size_t want = std::max<size_t>((size_t)1 << 30, lanes * per_lane / 4 * 5 * (c->wide ? 2 : 1));
+	/* (`-n 0`, the reference's default: a read's heap is its root entry - the search goes straight to the exact tail, :345 - so the pool is a
+	 * few chunks per lane instead of 170 GB, whose hipMalloc and hipFree were a quarter of a 10 M-read `align -n 0` run: round 6) */
+	if (c->kp.max_diff == 0) want = std::max<size_t>((size_t)256 << 20, lanes * (size_t)4096);
 	if (want > ceiling) want = ceiling;
 	if (getenv("BWB_POOL_GB") && *getenv("BWB_POOL_GB")) want = std::min<size_t>((size_t)atol(getenv("BWB_POOL_GB")) << 30, fr / 10 * 7);
 	if (want < ((size_t)256 << 20)) want = (size_t)256 << 20; /* floor (also what BWB_POOL_GB=0 selects, to test the re-run path: class 2 must still fit a read) */
@@ -710,14 +713,24 @@ template <typename P> static int build_dtab_t(bwb_hip_ctx *c, int K) {
 	const double t0 = wall_s();
 	ScratchClass &sc = c->cls[0];
 	const size_t isz = sizeof(Intv<P>);
-	const size_t half = (c->d_pool.bytes / 2) & ~(size_t)255;
+	/* scratch for the levels' lists: the two halves of the (idle) chunk pool when they are large enough for any index of this size - never more
+	 * intervals than one and a half times the BWT's rows plus one per K-mer, 2^30 at most - else (`-n 0` runs keep a small pool) a temporary
+	 * allocation of that size; when that fails, whatever the pool offers (a build that outgrows it leaves no table) */
+	const size_t need_half = std::min<size_t>((size_t)64 << 24, (size_t)(c->ix.length + c->ix.length / 2) + ((size_t)1 << (2 * K))) * isz;
+	DevMem tmp;
+	unsigned char *pool0 = c->d_pool.as<unsigned char>();
+	size_t half = (c->d_pool.bytes / 2) & ~(size_t)255;
+	if (half < need_half) {
+		if (tmp.alloc(2 * need_half) == hipSuccess) { pool0 = tmp.as<unsigned char>(); half = need_half; }
+		else (void)hipGetLastError();
+	}
 	const unsigned long long cap = half / isz;
 	DevMem entA, entB, bump;
 	const size_t nK = (size_t)1 << (2 * K);
 	HIPCHK(entA.alloc(nK * 32));
 	HIPCHK(entB.alloc(std::max<size_t>(nK / 4, 1) * 32));
 	HIPCHK(bump.alloc(8));
-	unsigned char *pool0 = c->d_pool.as<unsigned char>(), *pool1 = pool0 + half;
+	unsigned char *pool1 = pool0 + half;
 	/* level 0: the empty suffix - one interval, the whole index; no restart, no visit */
 	const Intv<P> root{ (P)0, (P)(c->ix.length - 1) };
 	const uint4 e0[2] = { make_uint4(0u, (1u << 15) | (1u << 16), 0u, 0u), make_uint4(0u, 0u, 0u, 0u) };
