@@ -54,3 +54,46 @@ def test_stored_pmc_profile_is_quoted_only_for_the_kernels_it_was_measured_on(mo
     monkeypatch.setattr(bench, "source_hash", lambda: "0" * 16)
     traffic, src = bench.measured_traffic(a, a.reads, "kl_search", dom)
     assert traffic is None and "other kernel sources" in src
+
+
+def test_pmc_summary_prices_every_dispatch_on_its_own(tmp_path):
+    """tools/pmc_traffic_summary.py on synthetic counter CSVs and launch logs: a slice's and the draining launch's bytes are told apart
+    (bucket requests tallied at 64 B get their second 64 B from the library's own per-launch bucket count), and bench.py turns them into a
+    SUM over a run's launches."""
+    import csv
+    import subprocess
+    import sys
+    out = tmp_path / "pmc"
+    for sub in ("calib", "rd", "wr"):
+        (out / sub).mkdir(parents=True)
+    def write(sub, rows):
+        with open(out / sub / "run_counter_collection.csv", "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writeheader()
+            w.writerows(rows)
+    write("calib", [{"Dispatch_Id": 1, "Kernel_Name": "k_coop", "Counter_Name": "TCC_EA0_RDREQ_sum", "Counter_Value": float(1 << 27)}])
+    ks = "void kl_search<unsigned long, false, true>(...)"
+    rd, wr, log = [], [], []
+    for d, (bk, meta, wreq, drains) in enumerate([(1000, 500, 300, False), (1200, 700, 340, False), (100, 90, 20, True)], start=1):
+        rd += [{"Dispatch_Id": d, "Kernel_Name": ks, "Counter_Name": "TCC_EA0_RDREQ_sum", "Counter_Value": bk + meta},
+               {"Dispatch_Id": d, "Kernel_Name": ks, "Counter_Name": "TCC_EA0_RDREQ_32B_sum", "Counter_Value": 0}]
+        wr += [{"Dispatch_Id": d, "Kernel_Name": ks, "Counter_Name": "WRITE_SIZE", "Counter_Value": wreq * 32 / 1024},
+               {"Dispatch_Id": d, "Kernel_Name": ks, "Counter_Name": "TCC_EA0_WRREQ_sum", "Counter_Value": wreq}]
+        log.append({"kernel": "kl_search", "class": 0, "slot": d - 1, "drains": drains, "ms": 5.0, "buckets": bk, "entries_stored": 10, "entries_loaded": 20, "records_loaded": 30})
+    write("rd", rd)
+    write("wr", wr)
+    for name in ("rd_launches.jsonl", "wr_launches.jsonl"):
+        open(out / name, "w").write("".join(json.dumps(l) + "\n" for l in log))
+    line = {"metric": "x", "config": {"genome_mb": 1.0, "reads_per_gpu_per_step": 10, "max_diff": 3, "read_len": 100, "flags": "-n 3"},
+            "roofline": {"kernels": {"kl_search": {"bucket_bytes_per_step": 1150 * 128, "device_bytes_per_step": 1150 * 128 + 60 * 16, "ms_per_launch": 5.0}}}}
+    open(out / "rd.json", "w").write(json.dumps(line) + "\n")
+    dst = tmp_path / "x_pmc.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_summary.py"), str(out), str(dst), "2"], check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+    pj = json.load(open(dst))
+    pl = pj["kl_search"]["per_launch"]
+    assert pl["slice"]["launches"] == 2 and pl["drain"]["launches"] == 1
+    # a launch's bytes: RDREQ x 64 + its buckets x 64 (the second half of a 128-byte bucket request) + its writes
+    want = [(1500 * 64 + 1000 * 64 + 300 * 32), (1900 * 64 + 1200 * 64 + 340 * 32), (190 * 64 + 100 * 64 + 20 * 32)]
+    assert [q["hbm_bytes"] for q in pl["launches"]] == want
+    assert pl["slice"]["hbm_bytes_per_launch"] == (want[0] + want[1]) / 2 and pl["drain"]["hbm_bytes_per_launch"] == want[2]
+    assert pl["launches"][0]["device_bytes"] == 1000 * 128 + 30 * 16 + 30 * 16
